@@ -1,0 +1,139 @@
+/*
+ * qmpc.h -- C ABI of the MI355X-native batched convex-MPC solver.
+ *
+ * This is the drop-in boundary for the MPC hot path of
+ * Derek-TH-Wang/quadruped_ctrl.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).
+ * Plain C: opaque handle, plain pointers and sizes, int return codes, no
+ * exceptions, no globals, no framework types.  The single-robot reference
+ * symbols of src/MPC_Ctrl/convexMPC_interface.h:40-48 are provided on top of
+ * this ABI by include/convexMPC_interface.h (libconvexmpc_shim.so).
+ *
+ * Memory layout (all arrays one row per robot, row-major, batch-major):
+ *   p[B][3] v[B][3] q[B][4] (w,x,y,z)  w[B][3]
+ *   r[B][12]   axis-major foot offsets, r[axis*4 + foot]
+ *              (src/MPC_Ctrl/RobotState.cpp:25-27)
+ *   yaw[B]
+ *   traj[B][12*h]   reference trajectory, 12 states per horizon step
+ *   gait[B][4*h]    u8 contact table, gait[step*4 + foot]
+ *                   (src/MPC_Ctrl/Gait.cpp:142-166)
+ *   weights[12] or [B][12], alpha[1] or [B], x_drag[1] or [B]
+ *                   (stride 0 = shared by the batch)
+ * Outputs:
+ *   grf[B][12]      float, world-frame ground reaction force of foot f at
+ *                   horizon step 0: grf[3*f + axis]  == get_solution(0..11)
+ *   soln[B][12*h]   optional double, the whole q_soln (zeros on swing feet,
+ *                   src/MPC_Ctrl/SolverMPC.cpp:545-557)
+ *   status[B]       per-robot status bits (QMPC_ST_*), 0 = solved
+ *   iters[B]        optional, active-set iterations used
+ */
+#ifndef QMPC_H
+#define QMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMPC_MAX_HORIZON 16 /* largest horizon the reference uses
+                               (src/MPC_Ctrl/ConvexMPCLocomotion.cpp:196,204) */
+
+/* return codes */
+#define QMPC_OK 0
+#define QMPC_ERR_ARG 1     /* bad argument (null, size, horizon > max) */
+#define QMPC_ERR_DEVICE 2  /* HIP runtime error (see qmpc_last_error) */
+#define QMPC_ERR_STATE 3   /* call order (solve before setup) */
+
+/* per-robot status bits */
+#define QMPC_ST_MAXITER 1    /* active-set iteration limit reached */
+#define QMPC_ST_NOT_PD 2     /* condensed Hessian not positive definite */
+#define QMPC_ST_INFEASIBLE 4 /* constraints inconsistent (cannot happen for
+                                friction pyramids with f_max >= 0) */
+#define QMPC_ST_WS_FULL 8    /* working-set capacity exceeded */
+
+typedef struct qmpc_ctx* qmpc_handle;
+
+/* Batched inputs.  Device pointers for qmpc_solve, host pointers for
+ * qmpc_solve_host.  Replaces struct update_data_t
+ * (src/MPC_Ctrl/convexMPC_interface.h:21-38). */
+typedef struct {
+  const float* p;
+  const float* v;
+  const float* q;
+  const float* w;
+  const float* r;
+  const float* yaw;
+  const float* traj;
+  const uint8_t* gait;
+  const float* weights;
+  const float* alpha;
+  const float* x_drag;
+  int weights_stride; /* 0 (shared) or 12 */
+  int alpha_stride;   /* 0 or 1 */
+  int x_drag_stride;  /* 0 or 1 */
+} qmpc_inputs;
+
+typedef struct {
+  float* grf;      /* [B][12]  required */
+  double* soln;    /* [B][12h] optional (NULL to skip) */
+  int32_t* status; /* [B]      required */
+  int32_t* iters;  /* [B]      optional */
+} qmpc_outputs;
+
+/* Create a solver bound to HIP device `device_id`.  Allocates the per-call
+ * work lists for up to max_batch robots and horizons up to max_horizon
+ * (<= QMPC_MAX_HORIZON).  Replaces the file-scope globals of
+ * src/MPC_Ctrl/convexMPC_interface.cpp:13-20 and SolverMPC.cpp:18-57. */
+int qmpc_create(int device_id, int max_batch, int max_horizon,
+                qmpc_handle* out);
+int qmpc_destroy(qmpc_handle h);
+
+/* Replaces setup_problem(dt, horizon, mu, f_max)
+ * (src/MPC_Ctrl/convexMPC_interface.cpp:42-66).  dt, mu and f_max are
+ * rounded to float exactly as struct problem_setup stores them. */
+int qmpc_setup(qmpc_handle h, double dt, int horizon, double mu, double f_max);
+
+/* Robot constants the reference hard-codes: mass 9 (RobotState.h:23),
+ * I_body diag(.07,.26,.242) (RobotState.cpp:38), gravity state -9.8
+ * (SolverMPC.cpp:318).  Optional; those literals are the defaults. */
+int qmpc_set_robot(qmpc_handle h, double mass, const double ibody_diag[3],
+                   double gravity);
+
+/* Replaces update_solver_settings (convexMPC_interface.cpp:107-119): the
+ * reference's JCQP knobs have no meaning for the exact active-set solve;
+ * what remains is the iteration cap (the role of nWSR=100,
+ * SolverMPC.cpp:435) and the constraint-violation tolerance [N]. */
+int qmpc_settings(qmpc_handle h, int max_iter, double tol);
+
+/* Solve `batch` independent MPC problems.  All pointers are DEVICE pointers
+ * valid on the handle's device; the call only enqueues work on `stream`
+ * (a hipStream_t, NULL = default stream) and returns; results are readable
+ * once the stream has been synchronised.  Replaces the blocking
+ * update_problem_data_floats(...) -> solve_mpc(...) -> get_solution(i)
+ * sequence (convexMPC_interface.cpp:121-180, SolverMPC.cpp:296-639). */
+int qmpc_solve(qmpc_handle h, int batch, const qmpc_inputs* in,
+               const qmpc_outputs* out, void* stream);
+
+/* Same with HOST pointers: copies in, solves, copies out, synchronises.
+ * This is what the single-robot reference shim uses. */
+int qmpc_solve_host(qmpc_handle h, int batch, const qmpc_inputs* in,
+                    const qmpc_outputs* out);
+
+/* Test hook: when non-NULL, the next qmpc_solve calls also store the
+ * assembled reduced QP of every robot (before the solve) into DEVICE
+ * buffers H[B][ld*ld], g[B][ld] (doubles, row-major, ld = qmpc_debug_ld();
+ * entries beyond n_r are padding).  Pass NULLs to switch off. */
+int qmpc_set_debug(qmpc_handle h, double* H_dev, double* g_dev);
+int qmpc_debug_ld(qmpc_handle h);
+
+/* Last HIP error string for this handle ("" if none). */
+const char* qmpc_last_error(qmpc_handle h);
+
+/* Library/ABI version, bumped on any signature change. */
+int qmpc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMPC_H */

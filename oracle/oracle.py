@@ -1,0 +1,188 @@
+"""ctypes loader for the parity oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.  It loads
+
+  * oracle/libmpc_oracle.so      C restatement of the reference assembly
+                                 (mpc_oracle.c; SolverMPC.cpp:296-525)
+  * oracle/_ref/libqpoases_ref.so  the reference's own qpOASES 3.2.0, driven
+                                 as SolverMPC.cpp:527-541 (qpoases_shim.cpp)
+
+and exposes a batched numpy front end.  Parity status: solver pinned by the
+real qpOASES; assembly unpinned (Eigen absent) -- see mpc_oracle.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAXH = 36
+
+
+class Setup(C.Structure):
+    _fields_ = [("dt", C.c_float), ("mu", C.c_float), ("f_max", C.c_float),
+                ("horizon", C.c_int)]
+
+
+class Update(C.Structure):
+    _fields_ = [("p", C.c_float * 3), ("v", C.c_float * 3),
+                ("q", C.c_float * 4), ("w", C.c_float * 3),
+                ("r", C.c_float * 12), ("yaw", C.c_float),
+                ("weights", C.c_float * 12),
+                ("traj", C.c_float * (12 * MAXH)), ("alpha", C.c_float),
+                ("gait", C.c_ubyte * (4 * MAXH)), ("x_drag", C.c_float)]
+
+
+_QPFN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                    C.c_void_p)
+
+_lib = None
+_ref = None
+
+
+def build():
+    """(Re)build the oracle libraries via oracle/Makefile."""
+    import subprocess
+    subprocess.run(["make", "-C", _HERE, "-j8"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libmpc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.oracle_solve_mpc.restype = C.c_int
+        _lib.oracle_reduce.restype = C.c_int
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libqpoases_ref.so"))
+
+
+def ref():
+    """The reference's qpOASES build (oracle/_ref)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libqpoases_ref.so")
+        if not os.path.exists(path):
+            build()
+        _ref = C.CDLL(path)
+        _ref.qpoases_ref_solve.restype = C.c_int
+        _ref.qpoases_ref_solve_ex.restype = C.c_int
+    return _ref
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_update(i, b):
+    """Pack instance i of a batch dict (quadruped_ctrl_amd.workloads layout)."""
+    u = Update()
+    h = b["horizon"]
+    u.p[:] = b["p"][i]
+    u.v[:] = b["v"][i]
+    u.q[:] = b["q"][i]
+    u.w[:] = b["w"][i]
+    u.r[:] = b["r"][i]
+    u.yaw = float(b["yaw"][i])
+    u.weights[:] = b["weights"][i]
+    u.traj[:12 * h] = b["traj"][i, :12 * h]
+    u.alpha = float(b["alpha"][i])
+    u.gait[:4 * h] = [int(x) for x in b["gait"][i, :4 * h]]
+    u.x_drag = float(b["x_drag"][i])
+    return u
+
+
+def make_setup(b):
+    return Setup(float(b["dt"]), float(b["mu"]), float(b["f_max"]),
+                 int(b["horizon"]))
+
+
+def assemble(b, i):
+    """Full-size QP of instance i: (H, g, A, lb, ub, x0) as the reference
+    hands them to the elimination step (SolverMPC.cpp:423-429)."""
+    h = b["horizon"]
+    n, m = 12 * h, 20 * h
+    H = np.zeros((n, n))
+    g = np.zeros(n)
+    A = np.zeros((m, n))
+    lb = np.zeros(m)
+    ub = np.zeros(m)
+    x0 = np.zeros(13, np.float32)
+    u, s = make_update(i, b), make_setup(b)
+    lib().oracle_assemble(C.byref(u), C.byref(s), _ptr(H), _ptr(g), _ptr(A),
+                          _ptr(lb), _ptr(ub), _ptr(x0))
+    return H, g, A, lb, ub, x0
+
+
+def reduce(H, g, A, lb, ub):
+    """Swing elimination (SolverMPC.cpp:441-525)."""
+    n, m = g.size, lb.size
+    ve = np.zeros(n, np.uint8)
+    Hr = np.zeros(n * n)
+    gr = np.zeros(n)
+    Ar = np.zeros(m * n)
+    lr = np.zeros(m)
+    ur = np.zeros(m)
+    nc = C.c_int(0)
+    nv = lib().oracle_reduce(n, m, _ptr(H), _ptr(g), _ptr(A), _ptr(lb),
+                             _ptr(ub), _ptr(ve), C.byref(nc), _ptr(Hr),
+                             _ptr(gr), _ptr(Ar), _ptr(lr), _ptr(ur))
+    nc = nc.value
+    return (ve.astype(bool), Hr[:nv * nv].reshape(nv, nv).copy(), gr[:nv].copy(),
+            Ar[:nc * nv].reshape(nc, nv).copy(), lr[:nc].copy(), ur[:nc].copy())
+
+
+def qpoases(H, g, A, lb, ub, nwsr=100):
+    """Real qpOASES, cold start, setToMPC (SolverMPC.cpp:527-541).
+    Returns (x, y_dual, nwsr_used, getPrimal_rc, init_rc)."""
+    nv, nc = g.size, lb.size
+    H = np.ascontiguousarray(H, np.float64)
+    A = np.ascontiguousarray(A, np.float64)
+    x = np.zeros(nv)
+    y = np.zeros(nv + nc)
+    used = C.c_int(0)
+    irc = C.c_int(0)
+    rc = ref().qpoases_ref_solve_ex(nv, nc, _ptr(H), _ptr(g), _ptr(A),
+                                    _ptr(lb), _ptr(ub), nwsr, _ptr(x),
+                                    C.byref(used), C.byref(irc), _ptr(y))
+    return x, y, used.value, rc, irc.value
+
+
+def solve_batch(b, idx=None):
+    """Reference pipeline (oracle assembly + real qpOASES) for instances idx.
+    Returns (q_soln[len(idx), 12h] float64, nwsr[len(idx)], rc[len(idx)])."""
+    h = b["horizon"]
+    idx = range(b["batch"]) if idx is None else idx
+    idx = list(idx)
+    out = np.zeros((len(idx), 12 * h))
+    nwsr = np.zeros(len(idx), np.int32)
+    rcs = np.zeros(len(idx), np.int32)
+    s = make_setup(b)
+    fn = C.cast(ref().qpoases_ref_solve, C.c_void_p)
+    lib().oracle_solve_mpc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+    for k, i in enumerate(idx):
+        u = make_update(i, b)
+        q = np.zeros(12 * h)
+        w = C.c_int(0)
+        rcs[k] = lib().oracle_solve_mpc(C.addressof(u), C.addressof(s), fn,
+                                        _ptr(q), C.addressof(w))
+        out[k] = q
+        nwsr[k] = w.value
+    return out, nwsr, rcs
+
+
+def mpc_table(n_segments, offsets, durations, iteration):
+    """Gait.cpp:142-166."""
+    t = (C.c_int * (4 * n_segments))()
+    lib().oracle_mpc_table(n_segments, (C.c_int * 4)(*offsets),
+                           (C.c_int * 4)(*durations), int(iteration), t)
+    return np.array(t[:], np.int32)

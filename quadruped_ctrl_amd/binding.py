@@ -1,0 +1,212 @@
+"""ctypes binding of the C ABI in include/qmpc.h (libqmpc.so).
+
+PyTorch is used only for device memory and streams; every solve goes through
+the hand-written HIP kernels in csrc/.  There is no CPU or PyTorch fallback:
+if libqmpc.so is missing or no HIP device is present this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libqmpc.so")
+
+QMPC_OK = 0
+ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL = 1, 2, 4, 8
+EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
+           "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
+           "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld"]
+
+
+class Inputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights",
+                 "alpha", "x_drag")] + [("weights_stride", C.c_int),
+                                        ("alpha_stride", C.c_int),
+                                        ("x_drag_stride", C.c_int)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("grf", C.c_void_p), ("soln", C.c_void_p),
+                ("status", C.c_void_p), ("iters", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libqmpc.so (built in-tree by __graft_entry__.build()).  Loud
+    failure when absent -- the product has no other compute path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()')")
+        lib = C.CDLL(LIB_PATH)
+        lib.qmpc_last_error.restype = C.c_char_p
+        lib.qmpc_last_error.argtypes = [C.c_void_p]
+        lib.qmpc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.qmpc_destroy.argtypes = [C.c_void_p]
+        lib.qmpc_setup.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double]
+        lib.qmpc_set_robot.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double), C.c_double]
+        lib.qmpc_settings.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.qmpc_solve.argtypes = [C.c_void_p, C.c_int, C.POINTER(Inputs),
+                                   C.POINTER(Outputs), C.c_void_p]
+        lib.qmpc_solve_host.argtypes = [C.c_void_p, C.c_int, C.POINTER(Inputs),
+                                        C.POINTER(Outputs)]
+        lib.qmpc_set_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.qmpc_debug_ld.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class QmpcError(RuntimeError):
+    pass
+
+
+class BatchedConvexMPC:
+    """Batched MPC solver on one GPU.
+
+    Host-side mirror of the reference's MPC interface
+    (src/MPC_Ctrl/convexMPC_interface.h:40-48) for B robots at once:
+    setup_problem -> setup(), update_problem_data_floats -> solve(),
+    get_solution(0..11) -> the returned grf[B,12].
+    """
+
+    def __init__(self, device=0, max_batch=65536, max_horizon=16):
+        import torch
+        if not torch.cuda.is_available():
+            raise QmpcError("no HIP device visible: quadruped_ctrl_amd has no CPU path")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = torch.device("cuda", device)
+        self.h = C.c_void_p()
+        rc = self.lib.qmpc_create(device, max_batch, max_horizon, C.byref(self.h))
+        if rc != QMPC_OK:
+            raise QmpcError(f"qmpc_create failed rc={rc}")
+        self.horizon = None
+        self._dbg = None
+
+    def close(self):
+        if self.h:
+            self.lib.qmpc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != QMPC_OK:
+            err = self.lib.qmpc_last_error(self.h).decode()
+            raise QmpcError(f"{what} failed rc={rc} {err}")
+
+    def setup(self, dt, horizon, mu, f_max):
+        self._check(self.lib.qmpc_setup(self.h, dt, horizon, mu, f_max), "qmpc_setup")
+        self.horizon = horizon
+
+    def set_robot(self, mass, ibody, gravity):
+        arr = (C.c_double * 3)(*ibody)
+        self._check(self.lib.qmpc_set_robot(self.h, mass, arr, gravity), "qmpc_set_robot")
+
+    def settings(self, max_iter=1000, tol=1e-9):
+        self._check(self.lib.qmpc_settings(self.h, max_iter, tol), "qmpc_settings")
+
+    # ---- device-resident path -------------------------------------------
+    def upload(self, b):
+        """numpy batch dict (workloads layout) -> dict of device tensors."""
+        t = self.torch
+        d = {}
+        for k in ("p", "v", "q", "w", "r", "yaw", "traj", "weights", "alpha", "x_drag"):
+            d[k] = t.from_numpy(np.ascontiguousarray(b[k], np.float32)).to(self.device)
+        d["gait"] = t.from_numpy(np.ascontiguousarray(b["gait"], np.uint8)).to(self.device)
+        d["batch"] = int(b["batch"])
+        return d
+
+    def alloc_outputs(self, batch, full=False, iters=True):
+        t = self.torch
+        o = {"grf": t.empty((batch, 12), dtype=t.float32, device=self.device),
+             "status": t.empty((batch,), dtype=t.int32, device=self.device)}
+        o["soln"] = (t.empty((batch, 12 * self.horizon), dtype=t.float64, device=self.device)
+                     if full else None)
+        o["iters"] = t.empty((batch,), dtype=t.int32, device=self.device) if iters else None
+        return o
+
+    def make_args(self, d, o):
+        """Pack ctypes argument structs once (for launch-only timing loops)."""
+        inp = Inputs()
+        for k in ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights", "alpha", "x_drag"):
+            setattr(inp, k, d[k].data_ptr())
+        B = d["batch"]
+        inp.weights_stride = 12 if d["weights"].dim() == 2 else 0
+        inp.alpha_stride = 1 if d["alpha"].numel() == B else 0
+        inp.x_drag_stride = 1 if d["x_drag"].numel() == B else 0
+        out = Outputs(o["grf"].data_ptr(),
+                      o["soln"].data_ptr() if o["soln"] is not None else None,
+                      o["status"].data_ptr(),
+                      o["iters"].data_ptr() if o["iters"] is not None else None)
+        return inp, out
+
+    def solve_async(self, batch, inp, out, stream=None):
+        """Enqueue one batched solve on `stream` (torch current stream by default)."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        rc = self.lib.qmpc_solve(self.h, batch, C.byref(inp), C.byref(out),
+                                 C.c_void_p(s.cuda_stream))
+        self._check(rc, "qmpc_solve")
+
+    def solve(self, b, full=False):
+        """Convenience: numpy batch dict in, numpy results out (device path)."""
+        d = self.upload(b)
+        o = self.alloc_outputs(d["batch"], full=full)
+        inp, out = self.make_args(d, o)
+        self.solve_async(d["batch"], inp, out)
+        self.torch.cuda.synchronize(self.device)
+        res = {"grf": o["grf"].cpu().numpy(), "status": o["status"].cpu().numpy(),
+               "iters": o["iters"].cpu().numpy()}
+        if full:
+            res["soln"] = o["soln"].cpu().numpy()
+        return res
+
+    # ---- host-pointer path (what the single-robot shim uses) -------------
+    def solve_host(self, b, full=False):
+        B, h = int(b["batch"]), self.horizon
+        keep = {k: np.ascontiguousarray(b[k], np.float32) for k in
+                ("p", "v", "q", "w", "r", "yaw", "traj", "weights", "alpha", "x_drag")}
+        keep["gait"] = np.ascontiguousarray(b["gait"], np.uint8)
+        inp = Inputs()
+        for k, a in keep.items():
+            setattr(inp, k, a.ctypes.data)
+        inp.weights_stride = 12 if keep["weights"].size == 12 * B else 0
+        inp.alpha_stride = 1 if keep["alpha"].size == B else 0
+        inp.x_drag_stride = 1 if keep["x_drag"].size == B else 0
+        grf = np.zeros((B, 12), np.float32)
+        st = np.zeros(B, np.int32)
+        it = np.zeros(B, np.int32)
+        soln = np.zeros((B, 12 * h)) if full else None
+        out = Outputs(grf.ctypes.data, soln.ctypes.data if full else None,
+                      st.ctypes.data, it.ctypes.data)
+        self._check(self.lib.qmpc_solve_host(self.h, B, C.byref(inp), C.byref(out)),
+                    "qmpc_solve_host")
+        res = {"grf": grf, "status": st, "iters": it}
+        if full:
+            res["soln"] = soln
+        return res
+
+    # ---- test hook ---------------------------------------------------------
+    def debug_dump(self, batch):
+        """Enable the assembled-QP dump; returns (H_dev, g_dev, ld) tensors."""
+        t = self.torch
+        ld = self.lib.qmpc_debug_ld(self.h)
+        H = t.zeros((batch, ld, ld), dtype=t.float64, device=self.device)
+        g = t.zeros((batch, ld), dtype=t.float64, device=self.device)
+        self._check(self.lib.qmpc_set_debug(self.h, H.data_ptr(), g.data_ptr()), "qmpc_set_debug")
+        self._dbg = (H, g)
+        return H, g, ld
+
+    def debug_off(self):
+        self.lib.qmpc_set_debug(self.h, None, None)
+        self._dbg = None

@@ -1,0 +1,299 @@
+// qmpc_capi.cpp -- host side of the C ABI declared in include/qmpc.h.
+//
+// Owns the per-handle device state that the reference keeps in file-scope
+// globals (src/MPC_Ctrl/convexMPC_interface.cpp:13-20, SolverMPC.cpp:18-57):
+// problem constants, the batch-constant coefficient tables, the size-class
+// work lists, and staging buffers for the host-pointer entry point.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qmpc.h"
+#include "qmpc_device.h"
+
+extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
+
+struct qmpc_ctx {
+  int device = 0;
+  int max_batch = 0, max_horizon = 0;
+  bool is_setup = false;
+  int horizon = 0;
+  double dt = 0, mu = 0, f_max = 0;
+  double mass = 9.0;                       // RobotState.h:23
+  double ibody[3] = {.07f, 0.26f, 0.242f}; // RobotState.cpp:38 (float literals)
+  double gravity = -9.8f;                  // SolverMPC.cpp:318
+  int max_iter = 1000;
+  double tol = 1e-9;
+  double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
+  int* d_lists = nullptr;      // [2][max_batch] robot ids for classes 2 and 3
+  int* d_counts = nullptr;     // [2]
+  double* dbg_H = nullptr;
+  double* dbg_g = nullptr;
+  // staging for qmpc_solve_host
+  void* d_stage = nullptr;
+  size_t stage_bytes = 0;
+  std::string err;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = 0;
+  explicit DeviceGuard(int dev) {
+    hipGetDevice(&prev);
+    if (prev != dev) hipSetDevice(dev);
+  }
+  ~DeviceGuard() { hipSetDevice(prev); }
+};
+
+int fail(qmpc_ctx* c, hipError_t e, const char* what) {
+  c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return QMPC_ERR_DEVICE;
+}
+
+#define HIP_TRY(ctx, call)                              \
+  do {                                                  \
+    hipError_t e__ = (call);                            \
+    if (e__ != hipSuccess) return fail(ctx, e__, #call); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int qmpc_abi_version(void) { return 1; }
+
+const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out) {
+  if (!out || max_batch <= 0 || max_horizon <= 0 || max_horizon > QMPC_MAX_HORIZON)
+    return QMPC_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+    return QMPC_ERR_DEVICE;
+  qmpc_ctx* c = new qmpc_ctx();
+  c->device = device_id;
+  c->max_batch = max_batch;
+  c->max_horizon = max_horizon;
+  DeviceGuard g(device_id);
+  const size_t H = (size_t)max_horizon;
+  hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
+  if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 2 * (size_t)max_batch);
+  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 2);
+  if (e != hipSuccess) {
+    qmpc_destroy(c);
+    return QMPC_ERR_DEVICE;
+  }
+  *out = c;
+  return QMPC_OK;
+}
+
+int qmpc_destroy(qmpc_handle h) {
+  if (!h) return QMPC_ERR_ARG;
+  {
+    DeviceGuard g(h->device);
+    if (h->d_tables) hipFree(h->d_tables);
+    if (h->d_lists) hipFree(h->d_lists);
+    if (h->d_counts) hipFree(h->d_counts);
+    if (h->d_stage) hipFree(h->d_stage);
+  }
+  delete h;
+  return QMPC_OK;
+}
+
+int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
+  if (!c) return QMPC_ERR_ARG;
+  if (horizon <= 0 || horizon > c->max_horizon || !(mu > 0) || !(dt > 0)) return QMPC_ERR_ARG;
+  // struct problem_setup stores floats (convexMPC_interface.h:13-19)
+  c->dt = (double)(float)dt;
+  c->mu = (double)(float)mu;
+  c->f_max = (double)(float)f_max;
+  c->horizon = horizon;
+  const int h = horizon;
+  // coefficient tables (see qmpc_device.h); A_ct^3 = 0 makes
+  // Adt^d Bdt = dt B + c_d A B + e_d A^2 B exact.
+  std::vector<double> t(3 * h + 9 * h * h);
+  double* coef = t.data();
+  double* ctab = t.data() + 3 * h;
+  const double d1 = c->dt;
+  for (int d = 0; d < h; ++d) {
+    coef[0 * h + d] = d1;
+    coef[1 * h + d] = (2.0 * d + 1.0) * d1 * d1 / 2.0;
+    const double dp = d + 1.0;
+    coef[2 * h + d] = (dp * dp * dp - (double)d * d * d) * d1 * d1 * d1 / 6.0;
+  }
+  for (int p = 0; p < 3; ++p)
+    for (int q = 0; q < 3; ++q)
+      for (int i = 0; i < h; ++i)
+        for (int j = 0; j < h; ++j) {
+          double s = 0.0;
+          for (int k = (i > j ? i : j); k < h; ++k) s += coef[p * h + (k - i)] * coef[q * h + (k - j)];
+          ctab[((p * 3 + q) * h + i) * h + j] = s;
+        }
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipMemcpy(c->d_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  c->is_setup = true;
+  return QMPC_OK;
+}
+
+int qmpc_set_robot(qmpc_handle c, double mass, const double ibody_diag[3], double gravity) {
+  if (!c || !ibody_diag || !(mass > 0)) return QMPC_ERR_ARG;
+  for (int k = 0; k < 3; ++k)
+    if (!(ibody_diag[k] > 0)) return QMPC_ERR_ARG;
+  c->mass = mass;
+  for (int k = 0; k < 3; ++k) c->ibody[k] = ibody_diag[k];
+  c->gravity = gravity;
+  return QMPC_OK;
+}
+
+int qmpc_settings(qmpc_handle c, int max_iter, double tol) {
+  if (!c || max_iter <= 0 || !(tol >= 0)) return QMPC_ERR_ARG;
+  c->max_iter = max_iter;
+  c->tol = tol;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
+  if (!c) return QMPC_ERR_ARG;
+  c->dbg_H = H_dev;
+  c->dbg_g = g_dev;
+  return QMPC_OK;
+}
+
+int qmpc_debug_ld(qmpc_handle) { return QMPC_DBG_LD; }
+
+int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out, void* stream_) {
+  if (!c || !in || !out) return QMPC_ERR_ARG;
+  if (!c->is_setup) return QMPC_ERR_STATE;
+  if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  if (!in->p || !in->v || !in->q || !in->w || !in->r || !in->yaw || !in->traj || !in->gait ||
+      !in->weights || !in->alpha || !in->x_drag || !out->grf || !out->status)
+    return QMPC_ERR_ARG;
+  if ((in->weights_stride != 0 && in->weights_stride != 12) || (in->alpha_stride & ~1) ||
+      (in->x_drag_stride & ~1))
+    return QMPC_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  DeviceGuard g(c->device);
+  const int h = c->horizon;
+
+  QmpcParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.p = in->p; P.v = in->v; P.q = in->q; P.w = in->w; P.r = in->r; P.yaw = in->yaw;
+  P.traj = in->traj; P.gait = in->gait; P.weights = in->weights; P.alpha = in->alpha;
+  P.x_drag = in->x_drag;
+  P.weights_stride = in->weights_stride;
+  P.alpha_stride = in->alpha_stride;
+  P.x_drag_stride = in->x_drag_stride;
+  P.grf = out->grf; P.soln = out->soln; P.status = out->status; P.iters = out->iters;
+  P.batch = batch; P.horizon = h;
+  P.dt = c->dt;
+  // fpt mu = 1.f/setup->mu  (SolverMPC.cpp:366), float arithmetic
+  const float mi = 1.f / (float)c->mu;
+  P.mu_inv = (double)mi;
+  P.inv_fr_norm = 1.0 / std::sqrt(P.mu_inv * P.mu_inv + 1.0);
+  P.f_max = c->f_max;
+  P.mass = c->mass;
+  for (int k = 0; k < 3; ++k) P.ibody[k] = c->ibody[k];
+  P.gravity = c->gravity;
+  P.coef = c->d_tables;
+  P.ctab = c->d_tables + 3 * h;
+  P.max_iter = c->max_iter;
+  P.tol = c->tol;
+  P.dbg_H = c->dbg_H;
+  P.dbg_g = c->dbg_g;
+
+  // size classes: n_r = 3 * stance foot-steps <= 64 / 128 / 192
+  const int nmax = 12 * h;
+  const int nclass = nmax <= 64 ? 1 : (nmax <= 128 ? 2 : 3);
+  if (nclass > 1) HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * 2, stream));
+  int* list2 = c->d_lists;
+  int* list3 = c->d_lists + c->max_batch;
+  // class 1: one workgroup per robot
+  P.list = nullptr; P.count = nullptr;
+  P.next_list = nclass > 1 ? list2 : nullptr;
+  P.next_count = nclass > 1 ? c->d_counts : nullptr;
+  HIP_TRY(c, qmpc_launch(1, &P, batch, stream));
+  const int pgrid = batch < 1024 ? batch : 1024;
+  if (nclass > 1) {
+    P.list = list2; P.count = c->d_counts;
+    P.next_list = nclass > 2 ? list3 : nullptr;
+    P.next_count = nclass > 2 ? c->d_counts + 1 : nullptr;
+    HIP_TRY(c, qmpc_launch(2, &P, pgrid, stream));
+  }
+  if (nclass > 2) {
+    P.list = list3; P.count = c->d_counts + 1;
+    P.next_list = nullptr; P.next_count = nullptr;
+    HIP_TRY(c, qmpc_launch(3, &P, pgrid, stream));
+  }
+  return QMPC_OK;
+}
+
+int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out) {
+  if (!c || !in || !out) return QMPC_ERR_ARG;
+  if (!c->is_setup) return QMPC_ERR_STATE;
+  if (batch <= 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (!in->p || !in->v || !in->q || !in->w || !in->r || !in->yaw || !in->traj || !in->gait ||
+      !in->weights || !in->alpha || !in->x_drag || !out->grf || !out->status)
+    return QMPC_ERR_ARG;
+  DeviceGuard g(c->device);
+  const size_t B = (size_t)batch, h = (size_t)c->horizon;
+  // carve one staging allocation (256-byte aligned pieces)
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t wN = in->weights_stride ? 12 * B : 12, aN = in->alpha_stride ? B : 1,
+               xN = in->x_drag_stride ? B : 1;
+  const size_t o_p = carve(4 * 3 * B), o_v = carve(4 * 3 * B), o_q = carve(4 * 4 * B),
+               o_w = carve(4 * 3 * B), o_r = carve(4 * 12 * B), o_yaw = carve(4 * B),
+               o_traj = carve(4 * 12 * h * B), o_gait = carve(4 * h * B), o_wt = carve(4 * wN),
+               o_al = carve(4 * aN), o_xd = carve(4 * xN), o_grf = carve(4 * 12 * B),
+               o_soln = carve(out->soln ? 8 * 12 * h * B : 0), o_st = carve(4 * B),
+               o_it = carve(out->iters ? 4 * B : 0);
+  if (off > c->stage_bytes) {
+    if (c->d_stage) hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->d_stage, off));
+    c->stage_bytes = off;
+  }
+  char* base = (char*)c->d_stage;
+  hipStream_t s = nullptr;
+#define H2D(o, src, bytes) HIP_TRY(c, hipMemcpyAsync(base + (o), (src), (bytes), hipMemcpyHostToDevice, s))
+  H2D(o_p, in->p, 4 * 3 * B); H2D(o_v, in->v, 4 * 3 * B); H2D(o_q, in->q, 4 * 4 * B);
+  H2D(o_w, in->w, 4 * 3 * B); H2D(o_r, in->r, 4 * 12 * B); H2D(o_yaw, in->yaw, 4 * B);
+  H2D(o_traj, in->traj, 4 * 12 * h * B); H2D(o_gait, in->gait, 4 * h * B);
+  H2D(o_wt, in->weights, 4 * wN); H2D(o_al, in->alpha, 4 * aN); H2D(o_xd, in->x_drag, 4 * xN);
+#undef H2D
+  qmpc_inputs din = *in;
+  din.p = (const float*)(base + o_p); din.v = (const float*)(base + o_v);
+  din.q = (const float*)(base + o_q); din.w = (const float*)(base + o_w);
+  din.r = (const float*)(base + o_r); din.yaw = (const float*)(base + o_yaw);
+  din.traj = (const float*)(base + o_traj); din.gait = (const uint8_t*)(base + o_gait);
+  din.weights = (const float*)(base + o_wt); din.alpha = (const float*)(base + o_al);
+  din.x_drag = (const float*)(base + o_xd);
+  qmpc_outputs dout;
+  dout.grf = (float*)(base + o_grf);
+  dout.soln = out->soln ? (double*)(base + o_soln) : nullptr;
+  dout.status = (int32_t*)(base + o_st);
+  dout.iters = out->iters ? (int32_t*)(base + o_it) : nullptr;
+  const int rc = qmpc_solve(c, batch, &din, &dout, s);
+  if (rc != QMPC_OK) return rc;
+#define D2H(dst, o, bytes) HIP_TRY(c, hipMemcpyAsync((dst), base + (o), (bytes), hipMemcpyDeviceToHost, s))
+  D2H(out->grf, o_grf, 4 * 12 * B);
+  if (out->soln) D2H(out->soln, o_soln, 8 * 12 * h * B);
+  D2H(out->status, o_st, 4 * B);
+  if (out->iters) D2H(out->iters, o_it, 4 * B);
+#undef D2H
+  HIP_TRY(c, hipStreamSynchronize(s));
+  return QMPC_OK;
+}
+
+}  // extern "C"

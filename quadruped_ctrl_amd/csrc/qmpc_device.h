@@ -1,0 +1,59 @@
+// qmpc_device.h -- kernel parameter block shared by qmpc_kernels.hip (device)
+// and qmpc_capi.cpp (host side of the C ABI in include/qmpc.h).
+#ifndef QMPC_DEVICE_H
+#define QMPC_DEVICE_H
+
+#include <stdint.h>
+
+// mirror of the QMPC_ST_* bits of include/qmpc.h
+#define QMPC_DEV_ST_MAXITER 1
+#define QMPC_DEV_ST_NOT_PD 2
+#define QMPC_DEV_ST_INFEASIBLE 4
+#define QMPC_DEV_ST_WS_FULL 8
+
+// leading dimension of the debug dump (largest padded size, 3 * 64)
+#define QMPC_DBG_LD 192
+
+struct QmpcParams {
+  // batched inputs (device pointers; layouts in include/qmpc.h)
+  const float* p;
+  const float* v;
+  const float* q;
+  const float* w;
+  const float* r;
+  const float* yaw;
+  const float* traj;
+  const uint8_t* gait;
+  const float* weights;
+  const float* alpha;
+  const float* x_drag;
+  int weights_stride, alpha_stride, x_drag_stride;
+  // outputs
+  float* grf;
+  double* soln;
+  int32_t* status;
+  int32_t* iters;
+  // problem constants (problem_setup of convexMPC_interface.h:13-19, rounded
+  // to float like the reference stores them, then widened)
+  int batch, horizon;
+  double dt, mu_inv, inv_fr_norm, f_max;
+  double mass, ibody[3], gravity;
+  // batch-constant tables built at qmpc_setup():
+  //   coef[p][d]   p<3, d<h     dt, (2d+1)dt^2/2, ((d+1)^3-d^3)dt^3/6
+  //   ctab[pq][i][j] pq<9       sum_{k>=max(i,j)} coef_p(k-i) coef_q(k-j)
+  const double* coef;
+  const double* ctab;
+  // solver settings
+  int max_iter;
+  double tol;
+  // work lists: robots handed from one size class to the next
+  const int* list;   // nullptr: robot = blockIdx.x
+  const int* count;
+  int* next_list;    // nullptr: no larger class available
+  int* next_count;
+  // debug dump (nullptr = off)
+  double* dbg_H;
+  double* dbg_g;
+};
+
+#endif

@@ -1,0 +1,136 @@
+"""Synthetic batched robot states for the five BASELINE.json configs.
+
+Generators follow SURVEY.md section 8(d) literally (seed = 20260928 + config
+index, numpy default_rng).  Output is a dict of numpy arrays in the layout
+the C-ABI (include/qmpc.h) consumes: one row per robot, row-major.
+
+    p[B,3] v[B,3] q[B,4](w,x,y,z) w[B,3] r[B,12](axis-major, r[axis*4+foot])
+    yaw[B] weights[B,12] traj[B,12h] alpha[B] x_drag[B] gait[B,4h](u8)
+
+Contact tables come from the OffsetDurationGait rule of the reference
+(Gait.cpp:142-166), re-implemented in gait.mpc_table.
+"""
+import numpy as np
+
+from .gait import mpc_table
+
+SEED0 = 20260928
+DT_MPC = 13 * 0.002            # GaitCtrller.cpp:6, config freq 500 Hz
+MU = 0.4                       # ConvexMPCLocomotion.cpp:630
+F_MAX = 120.0
+ALPHA = 4e-5                   # ConvexMPCLocomotion.cpp:604
+Q_WEIGHTS = np.array([2.5, 2.5, 10, 50, 50, 100, 0, 0, 0.5, 0.2, 0.2, 0.1],
+                     np.float32)  # ConvexMPCLocomotion.cpp:598
+
+# h=10 rescalings of the reference's 14-segment gaits
+# (ConvexMPCLocomotion.cpp:27-29,40), SURVEY.md 8(d) config 3.
+GAITS_H10 = {
+    "trot": ((0, 5, 5, 0), (5, 5, 5, 5)),
+    "bounding": ((5, 5, 0, 0), (4, 4, 4, 4)),
+    "pacing": ((5, 0, 5, 0), (5, 5, 5, 5)),
+    "standing": ((0, 0, 0, 0), (10, 10, 10, 10)),
+}
+GAITS_H16 = {"trot": ((0, 8, 8, 0), (8, 8, 8, 8))}
+
+
+def _quat_from_rpy(rpy):
+    """ZYX Euler -> (w,x,y,z); inverse of quat_to_rpy (SolverMPC.cpp:257-267)."""
+    r, p, y = rpy[:, 0] / 2, rpy[:, 1] / 2, rpy[:, 2] / 2
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.stack([cr * cp * cy + sr * sp * sy,
+                     sr * cp * cy - cr * sp * sy,
+                     cr * sp * cy + sr * cp * sy,
+                     cr * cp * sy - sr * sp * cy], 1)
+
+
+def _states(rng, B, h, stairs=False):
+    p = np.array([0, 0, 0.29]) + rng.normal(0, 0.01, (B, 3))
+    v = np.array([0.5, 0, 0]) + rng.normal(0, 0.1, (B, 3))
+    rpy = rng.normal(0, 0.05, (B, 3))
+    w = rng.normal(0, 0.2, (B, 3))
+    feet = np.array([[.19, .19, -.19, -.19],
+                     [-.111, .111, -.111, .111],
+                     [-.29, -.29, -.29, -.29]])
+    r = feet[None] + rng.normal(0, 0.02, (B, 3, 4))
+    if stairs:
+        rpy[:, 0:2] = rng.uniform(-0.3, 0.3, (B, 2))
+        v[:, 2] = rng.normal(0, 0.2, B)
+        r[:, 2, :] += rng.choice([0, 0.02, 0.04, 0.06, 0.08], (B, 4))
+    q = _quat_from_rpy(rpy)
+    traj = np.zeros((B, h, 12))
+    traj[:, :, 2] = rpy[:, 2:3]
+    traj[:, :, 3] = p[:, 0:1] + v[:, 0:1] * DT_MPC * np.arange(h)[None]
+    traj[:, :, 4] = p[:, 1:2]
+    traj[:, :, 5] = 0.25
+    traj[:, :, 9] = 0.5
+    f32 = np.float32
+    return dict(p=p.astype(f32), v=v.astype(f32), q=q.astype(f32),
+                w=w.astype(f32), r=r.reshape(B, 12).astype(f32),
+                yaw=rpy[:, 2].astype(f32),
+                traj=traj.reshape(B, 12 * h).astype(f32))
+
+
+def _finish(d, B, h, gait):
+    d.update(batch=B, horizon=h, dt=DT_MPC, mu=MU, f_max=F_MAX,
+             weights=np.tile(Q_WEIGHTS, (B, 1)),
+             alpha=np.full(B, ALPHA, np.float32),
+             x_drag=np.zeros(B, np.float32),
+             gait=np.ascontiguousarray(gait, np.uint8))
+    return d
+
+
+def _gait_tables(rng, B, h, names, table):
+    which = rng.integers(0, len(names), B)
+    it = rng.integers(0, h, B)
+    g = np.zeros((B, 4 * h), np.uint8)
+    for i in range(B):
+        off, dur = table[names[which[i]]]
+        g[i] = mpc_table(h, off, dur, int(it[i]))
+    return g
+
+
+def make_config(idx, batch=None):
+    """BASELINE.json configs[idx] (0..4); `batch` overrides the batch size."""
+    rng = np.random.default_rng(SEED0 + idx)
+    if idx in (0, 1):
+        B, h = (batch or (1 if idx == 0 else 1024)), 10
+        d = _states(rng, B, h)
+        return _finish(d, B, h, _gait_tables(rng, B, h, ["trot"], GAITS_H10))
+    if idx == 2:
+        B, h = (batch or 4096), 10
+        d = _states(rng, B, h)
+        return _finish(d, B, h, _gait_tables(
+            rng, B, h, ["trot", "bounding", "pacing"], GAITS_H10))
+    if idx == 3:
+        B, h = (batch or 16384), 16
+        d = _states(rng, B, h)
+        return _finish(d, B, h, _gait_tables(rng, B, h, ["trot"], GAITS_H16))
+    if idx == 4:
+        B, h = (batch or 65536), 10
+        d = _states(rng, B, h, stairs=True)
+        g = (rng.random((B, h, 4)) < 0.5).astype(np.uint8)
+        none0 = g[:, 0, :].sum(1) == 0      # >= 1 stance foot at step 0
+        g[none0, 0, rng.integers(0, 4, none0.sum())] = 1
+        return _finish(d, B, h, g.reshape(B, 4 * h))
+    raise ValueError(idx)
+
+
+def make_standing(batch, horizon=10, seed=99):
+    """All four feet in stance for every step (n_r = 12h): the reference's
+    'Standing' gait (ConvexMPCLocomotion.cpp:35) -- largest reduced QP."""
+    rng = np.random.default_rng(SEED0 + seed)
+    d = _states(rng, batch, horizon)
+    d["traj"].reshape(batch, horizon, 12)[:, :, 9] = 0
+    d["traj"].reshape(batch, horizon, 12)[:, :, 3] = d["p"][:, 0:1]
+    return _finish(d, batch, horizon, np.ones((batch, 4 * horizon), np.uint8))
+
+
+def shard(d, rank, world):
+    """Contiguous batch slice [rank*ceil(B/world), ...) -- SURVEY.md 8(e)."""
+    B = d["batch"]
+    per = -(-B // world)
+    lo, hi = min(rank * per, B), min((rank + 1) * per, B)
+    out = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v)
+           for k, v in d.items()}
+    out["batch"] = hi - lo
+    return out
