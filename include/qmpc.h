@@ -126,6 +126,9 @@ int qmpc_solve_host(qmpc_handle h, int batch, const qmpc_inputs* in,
  * entries beyond n_r are padding).  Pass NULLs to switch off. */
 int qmpc_set_debug(qmpc_handle h, double* H_dev, double* g_dev);
 int qmpc_debug_ld(qmpc_handle h);
+/* Profiling hook: DEVICE buffer clk[B][16] receiving shader-clock stamps at
+ * the kernel's phase boundaries (NULL = off). */
+int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);
 
 /* Last HIP error string for this handle ("" if none). */
 const char* qmpc_last_error(qmpc_handle h);

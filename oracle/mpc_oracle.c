@@ -110,12 +110,18 @@ void oracle_ct_ss_mats(const float r[12], float yaw, float x_drag, float* A,
 /* dense float matmul C(rxc) = A(rxk) B(kxc), row-major */
 static void matmul_f(const float* A, const float* B, float* C, int r, int k,
                      int c) {
-  for (int i = 0; i < r; i++)
-    for (int j = 0; j < c; j++) {
-      float s = 0.f;
-      for (int l = 0; l < k; l++) s += A[i * k + l] * B[l * c + j];
-      C[i * c + j] = s;
+  /* i-l-j loop order: every C[i][j] still accumulates its k products in
+   * sequence l = 0..k-1 (identical rounding to the textbook dot-product
+   * loop), but the inner loop is unit-stride so gcc can vectorise it. */
+  for (int i = 0; i < r; i++) {
+    float* Ci = C + (size_t)i * c;
+    for (int j = 0; j < c; j++) Ci[j] = 0.f;
+    for (int l = 0; l < k; l++) {
+      const float a = A[i * k + l];
+      const float* Bl = B + (size_t)l * c;
+      for (int j = 0; j < c; j++) Ci[j] += a * Bl[j];
     }
+  }
 }
 
 /* SolverMPC.cpp:89-95.  The reference evaluates Eigen's float Pade expm of
@@ -206,14 +212,27 @@ void oracle_assemble(const oracle_update_t* u, const oracle_setup_t* s,
   for (int i = 0; i < ns; i++)
     for (int j = 0; j < n; j++)
       SB[(size_t)i * n + j] = Sd[i] * B_qp[(size_t)i * n + j];
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) {
-      float acc = 0.f;
-      for (int k = 0; k < ns; k++)
-        acc += B_qp[(size_t)k * n + i] * SB[(size_t)k * n + j];
-      if (i == j) acc += u->alpha;
-      H[(size_t)i * n + j] = (double)(2.f * acc); /* :423 matrix_to_real */
+  {
+    /* k-outer order: per element the same sequential sum over k, unit-stride
+     * inner loop (see matmul_f). */
+    float* Hf = (float*)calloc((size_t)n * n, sizeof(float));
+    for (int k = 0; k < ns; k++) {
+      const float* Bk = B_qp + (size_t)k * n;
+      const float* SBk = SB + (size_t)k * n;
+      for (int i = 0; i < n; i++) {
+        const float bki = Bk[i];
+        float* Hi = Hf + (size_t)i * n;
+        for (int j = 0; j < n; j++) Hi[j] += bki * SBk[j];
+      }
     }
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        float acc = Hf[(size_t)i * n + j];
+        if (i == j) acc += u->alpha;
+        H[(size_t)i * n + j] = (double)(2.f * acc); /* :423 matrix_to_real */
+      }
+    free(Hf);
+  }
   /* :399  qg = 2 B^T S (A_qp x0 - X_d) */
   float* t = (float*)malloc(sizeof(float) * ns);
   for (int i = 0; i < ns; i++) {
@@ -342,6 +361,20 @@ int oracle_solve_mpc(const oracle_update_t* u, const oracle_setup_t* s,
   free(H); free(g); free(Ac); free(lb); free(ub);
   free(Hr); free(gr); free(Ar); free(lr); free(ur); free(qr); free(ve);
   return rc;
+}
+
+/* The same, over `count` packed records; used for CPU-baseline timing so that
+ * no Python sits inside the timed loop.  q_soln is [count][12h]. */
+int oracle_solve_mpc_batch(const oracle_update_t* u, int count,
+                           const oracle_setup_t* s, oracle_qp_fn qp,
+                           double* q_soln, int* nwsr_out) {
+  int bad = 0;
+  for (int i = 0; i < count; i++) {
+    int nw = 0;
+    bad += oracle_solve_mpc(&u[i], s, qp, q_soln + (size_t)i * 12 * s->horizon, &nw) != 0;
+    if (nwsr_out) nwsr_out[i] = nw;
+  }
+  return bad;
 }
 
 /* Gait.cpp:142-166 */

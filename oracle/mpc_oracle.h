@@ -98,6 +98,11 @@ int oracle_reduce(int n, int m, const double* H, const double* g,
 int oracle_solve_mpc(const oracle_update_t* u, const oracle_setup_t* s,
                      oracle_qp_fn qp, double* q_soln, int* nwsr_out);
 
+/* Batched form of the above for baseline timing; returns #failures. */
+int oracle_solve_mpc_batch(const oracle_update_t* u, int count,
+                           const oracle_setup_t* s, oracle_qp_fn qp,
+                           double* q_soln, int* nwsr_out);
+
 /* Gait.cpp:142-166 OffsetDurationGait::getMpcTable with _iteration given
  * (Gait.cpp:189).  table[4*n_segments]. */
 void oracle_mpc_table(int n_segments, const int offsets[4],

@@ -180,6 +180,31 @@ def solve_batch(b, idx=None):
     return out, nwsr, rcs
 
 
+def pack_updates(b, idx=None):
+    """Contiguous array of Update records (for the C batch entry point)."""
+    idx = list(range(b["batch"])) if idx is None else list(idx)
+    arr = (Update * len(idx))()
+    for k, i in enumerate(idx):
+        arr[k] = make_update(i, b)
+    return arr
+
+
+def solve_packed(arr, b):
+    """Reference pipeline over pre-packed records, loop in C (timing-clean).
+    Returns (q_soln[count,12h], nwsr[count], n_failed)."""
+    h = b["horizon"]
+    n = len(arr)
+    out = np.zeros((n, 12 * h))
+    nwsr = np.zeros(n, np.int32)
+    s = make_setup(b)
+    fn = C.cast(ref().qpoases_ref_solve, C.c_void_p)
+    f = lib().oracle_solve_mpc_batch
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
+    bad = f(C.addressof(arr), n, C.addressof(s), fn, _ptr(out), _ptr(nwsr))
+    return out, nwsr, bad
+
+
 def mpc_table(n_segments, offsets, durations, iteration):
     """Gait.cpp:142-166."""
     t = (C.c_int * (4 * n_segments))()

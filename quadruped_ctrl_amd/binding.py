@@ -16,7 +16,8 @@ QMPC_OK = 0
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL = 1, 2, 4, 8
 EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
-           "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld"]
+           "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
+           "qmpc_set_debug_clock"]
 
 
 class Inputs(C.Structure):
@@ -58,6 +59,7 @@ def load_library():
                                         C.POINTER(Outputs)]
         lib.qmpc_set_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
+        lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -207,6 +209,15 @@ class BatchedConvexMPC:
         self._dbg = (H, g)
         return H, g, ld
 
+    def debug_clock(self, batch):
+        """Enable per-phase shader-clock stamps; returns the [batch,16] tensor."""
+        t = self.torch
+        clk = t.zeros((batch, 16), dtype=t.int64, device=self.device)
+        self._check(self.lib.qmpc_set_debug_clock(self.h, clk.data_ptr()), "qmpc_set_debug_clock")
+        self._clk = clk
+        return clk
+
     def debug_off(self):
+        self.lib.qmpc_set_debug_clock(self.h, None)
         self.lib.qmpc_set_debug(self.h, None, None)
         self._dbg = None

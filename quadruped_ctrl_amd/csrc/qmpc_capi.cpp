@@ -33,6 +33,7 @@ struct qmpc_ctx {
   int* d_counts = nullptr;     // [2]
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
+  long long* dbg_clk = nullptr;
   // staging for qmpc_solve_host
   void* d_stage = nullptr;
   size_t stage_bytes = 0;
@@ -166,6 +167,12 @@ int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
 
 int qmpc_debug_ld(qmpc_handle) { return QMPC_DBG_LD; }
 
+int qmpc_set_debug_clock(qmpc_handle c, long long* clk_dev) {
+  if (!c) return QMPC_ERR_ARG;
+  c->dbg_clk = clk_dev;
+  return QMPC_OK;
+}
+
 int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out, void* stream_) {
   if (!c || !in || !out) return QMPC_ERR_ARG;
   if (!c->is_setup) return QMPC_ERR_STATE;
@@ -206,6 +213,7 @@ int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outpu
   P.tol = c->tol;
   P.dbg_H = c->dbg_H;
   P.dbg_g = c->dbg_g;
+  P.dbg_clk = c->dbg_clk;
 
   // size classes: n_r = 3 * stance foot-steps <= 64 / 128 / 192
   const int nmax = 12 * h;

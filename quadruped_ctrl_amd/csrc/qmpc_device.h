@@ -54,6 +54,7 @@ struct QmpcParams {
   // debug dump (nullptr = off)
   double* dbg_H;
   double* dbg_g;
+  long long* dbg_clk;  // [batch][16] shader-clock stamps per phase
 };
 
 #endif

@@ -111,6 +111,12 @@ struct Smem {
 
 enum { ST_NEXT = 0, ST_INNER = 1, ST_DONE = 2 };
 
+// phase timestamps (test/profiling hook; P.dbg_clk == nullptr in production)
+#define QMPC_TICK(k)                                                        \
+  do {                                                                     \
+    if (P.dbg_clk && tid == 0) P.dbg_clk[(size_t)rid * 16 + (k)] = clock64(); \
+  } while (0)
+
 template <int RB>
 __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   constexpr int NP = 64 * RB, CW = 16 * RB, NT = 256 * RB;
@@ -121,6 +127,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   const int h = P.horizon;
   const int nfs = 4 * h;    // foot-steps in the horizon (<= 64)
 
+  QMPC_TICK(0);
   // ------------------------------------------------------------ phase 0a
   // contact table -> compact stance list (SolverMPC.cpp:441-469 finds the same
   // set by scanning for ub ~ 0 rows).
@@ -171,6 +178,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   const double x_drag = (double)P.x_drag[(size_t)rid * P.x_drag_stride];
   const double alpha = (double)P.alpha[(size_t)rid * P.alpha_stride];
 
+  QMPC_TICK(1);
   // ------------------------------------------------------------ phase 0b
   // scalars: yaw rotation, world inertia inverse, x0 (SolverMPC.cpp:315-319,
   // RobotState.cpp:30-40).  Transcendentals in float like the reference
@@ -226,6 +234,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   }
   __syncthreads();
 
+  QMPC_TICK(2);
   // ------------------------------------------------------------ phase 0c
   // B0 = B_ct (SolverMPC.cpp:246-253); free-response pieces A x0, A^2 x0.
   if (tid < 156) {
@@ -282,6 +291,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   }
   __syncthreads();
 
+  QMPC_TICK(3);
   // ------------------------------------------------------------ phase 0d
   // E_pq = B_p^T W B_q  and  s_p,i = sum_{k>=i} coef_p(k-i) e_k
   for (int idx = tid; idx < 9 * 144; idx += NT) {
@@ -290,7 +300,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
     double s = 0.0;
 #pragma unroll
     for (int row = 0; row < 12; ++row)
-      s += Aa.W[row] * Aa.B[pp][row * 12 + u] * Aa.B[qq][row * 12 + v];
+      s += Aa.W[row] * (Aa.B[pp][row * 12 + u] * Aa.B[qq][row * 12 + v]);  // E_qp = E_pq^T bitwise
     Aa.E[pq][uv] = s;
   }
   for (int idx = tid; idx < h * h; idx += NT) {
@@ -306,6 +316,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   }
   __syncthreads();
 
+  QMPC_TICK(4);
   // ------------------------------------------------------------ phase 1
   // gradient g_red and Hessian rows straight into registers.
   if (tid < n) {
@@ -356,9 +367,13 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
         if (rowok && j < n) {
           const int kj = S.sidx[j / 3];
           const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + (j % 3);
-          double acc = 0.0;
-#pragma unroll
-          for (int pq = 0; pq < 9; ++pq) acc += P.ctab[pq * hh + cidx] * Aa.E[pq][eidx];
+          // summed so that H[i][j] == H[j][i] bitwise: (p,q) and (q,p) terms
+          // are paired, and ctab[qp][sj][si] == ctab[pq][si][sj], E_qp = E_pq^T
+          auto term = [&](int pq) { return P.ctab[pq * hh + cidx] * Aa.E[pq][eidx]; };
+          double acc = term(0) + term(4) + term(8);
+          acc += term(1) + term(3);
+          acc += term(2) + term(6);
+          acc += term(5) + term(7);
           if (i == j) acc += alpha;
           val = 2.0 * acc;
         }
@@ -375,6 +390,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   }
   __syncthreads();  // Asm storage dead from here on (g, sidx, fmaxk are not in the union)
 
+  QMPC_TICK(5);
   // ------------------------------------------------------------ phase 2
   // n symmetric Gauss-Jordan sweeps: a <- -H^-1, one barrier per pivot.
   // Pivot column k is owned by column group k / CW in register k % CW; it is
@@ -413,6 +429,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   }
 
   auto& Sb = S.u.b;
+  QMPC_TICK(6);
   // ------------------------------------------------------------ phase 3
   // unconstrained minimiser x = -H^-1 g = a * g   (distributed mat-vec)
   {
@@ -437,6 +454,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   if (tid < NP) S.x[tid] = Sb.part[0][tid] + Sb.part[1][tid] + Sb.part[2][tid] + Sb.part[3][tid];
   __syncthreads();
 
+  QMPC_TICK(7);
   // ------------------------------------------------------------ phase 4
   // Goldfarb-Idnani dual active set on the explicit inverse.  Wave 0 is the
   // engine (all small algebra, no block barriers inside a step); the other
@@ -682,6 +700,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
     }
   }
 
+  QMPC_TICK(8);
   // ------------------------------------------------------------ outputs
   // get_solution(0..11): forces of the four feet at horizon step 0
   // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685).
@@ -703,6 +722,7 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
     if (P.iters) P.iters[rid] = S.iters;
   }
   __syncthreads();
+  QMPC_TICK(9);
 }
 
 }  // namespace

@@ -1,0 +1,100 @@
+"""CPU suite: host-side logic and the C-ABI surface (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from quadruped_ctrl_amd import binding, gait, workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_once():
+    import __graft_entry__ as g
+    g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _build_once()
+    hdr = open(os.path.join(ROOT, "include", "qmpc.h")).read()
+    declared = sorted(set(re.findall(r"\b(qmpc_[a-z_]+)\s*\(", hdr)))
+    assert set(declared) == set(binding.EXPORTS), (declared, binding.EXPORTS)
+    lib = C.CDLL(binding.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.qmpc_abi_version() == 1
+
+
+def test_shim_exports_reference_symbols():
+    _build_once()
+    path = os.path.join(ROOT, "quadruped_ctrl_amd", "libconvexmpc_shim.so")
+    if not os.path.exists(path):
+        pytest.skip("shim not built yet")
+    lib = C.CDLL(path)
+    # src/MPC_Ctrl/convexMPC_interface.h:40-48
+    for name in ("setup_problem", "update_problem_data", "get_solution",
+                 "update_solver_settings", "update_problem_data_floats"):
+        assert hasattr(lib, name), name
+
+
+def test_argument_validation_without_gpu():
+    _build_once()
+    lib = binding.load_library()
+    h = C.c_void_p()
+    assert lib.qmpc_create(0, 0, 10, C.byref(h)) == 1          # bad batch
+    assert lib.qmpc_create(0, 16, 99, C.byref(h)) == 1         # horizon > max
+    assert lib.qmpc_setup(None, 0.026, 10, 0.4, 120.0) == 1
+    assert lib.qmpc_destroy(None) == 1
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(binding.QmpcError):
+        binding.BatchedConvexMPC(0)
+
+
+def test_mpc_table_matches_reference_rule():
+    # Gait.cpp:142-166 restated in C (oracle) vs the vectorised host version
+    for n, off, dur in [(10, (0, 5, 5, 0), (5, 5, 5, 5)), (10, (5, 5, 0, 0), (4, 4, 4, 4)),
+                        (14, (0, 4, 7, 11), (7, 7, 7, 7)), (16, (0, 8, 8, 0), (8, 8, 8, 8)),
+                        (14, (0, 0, 0, 0), (14, 14, 14, 14))]:
+        for it in range(n):
+            assert np.array_equal(gait.mpc_table(n, off, dur, it), O.mpc_table(n, off, dur, it))
+    # trot, iteration 0: step i uses phase (i+1)%10; feet 0,3 stance for phase<5
+    t = gait.mpc_table(10, (0, 5, 5, 0), (5, 5, 5, 5), 0).reshape(10, 4)
+    assert t[0].tolist() == [1, 0, 0, 1] and t[4].tolist() == [0, 1, 1, 0]
+    assert np.all(t.sum(1) == 2)
+    g = gait.OffsetDurationGait(10, (0, 5, 5, 0), (5, 5, 5, 5), "Trotting")
+    g.setIterations(13, 13 * 3 + 5)
+    assert g.iteration == 3 and abs(g.phase - (13 * 3 + 5) / 130.0) < 1e-7
+    assert np.array_equal(g.getMpcTable(), gait.mpc_table(10, (0, 5, 5, 0), (5, 5, 5, 5), 3))
+
+
+@pytest.mark.parametrize("idx,B,h", [(0, 1, 10), (1, 1024, 10), (2, 4096, 10), (3, 16384, 16), (4, 65536, 10)])
+def test_workload_shapes(idx, B, h):
+    small = 32
+    b = W.make_config(idx, batch=small)
+    assert b["horizon"] == h and b["batch"] == small
+    assert b["traj"].shape == (small, 12 * h) and b["gait"].shape == (small, 4 * h)
+    assert b["gait"].dtype == np.uint8 and b["p"].dtype == np.float32
+    np.testing.assert_allclose(np.linalg.norm(b["q"], axis=1), 1, atol=1e-6)
+    if idx == 4:
+        assert np.all(b["gait"].reshape(small, h, 4)[:, 0].sum(1) >= 1)
+    if idx in (1, 3):
+        assert np.all(b["gait"].sum(1) == 2 * h)
+    # deterministic
+    b2 = W.make_config(idx, batch=small)
+    assert all(np.array_equal(b[k], b2[k]) for k in ("p", "gait", "traj"))
+
+
+def test_shard_is_disjoint_cover():
+    b = W.make_config(2, batch=37)
+    parts = [W.shard(b, r, 4) for r in range(4)]
+    assert sum(p["batch"] for p in parts) == 37
+    assert np.array_equal(np.concatenate([p["p"] for p in parts]), b["p"])
+    assert np.array_equal(np.concatenate([p["gait"] for p in parts]), b["gait"])

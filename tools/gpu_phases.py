@@ -1,0 +1,29 @@
+"""Scratch profiling aid: per-phase shader-clock breakdown of the solve kernel."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from quadruped_ctrl_amd import workloads as W
+from quadruped_ctrl_amd.binding import BatchedConvexMPC
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+b = W.make_config(cfg, batch=B)
+mpc = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
+mpc.setup(b["dt"], b["horizon"], b["mu"], b["f_max"])
+d = mpc.upload(b); o = mpc.alloc_outputs(B); inp, out = mpc.make_args(d, o)
+for _ in range(3): mpc.solve_async(B, inp, out)
+torch.cuda.synchronize()
+clk = mpc.debug_clock(B)
+mpc.solve_async(B, inp, out); torch.cuda.synchronize()
+c = clk.cpu().numpy().astype(np.float64)
+it = o["iters"].cpu().numpy()
+names = ["0a gait", "0b scalars", "0c B/e", "0d E/s", "1 asm H", "2 sweep", "3 x_u", "4 active set", "out"]
+d = np.diff(c[:, :10], axis=1)
+print(f"cfg{cfg} B={B}: per-phase shader cycles (median / mean / max over blocks); iters mean {it.mean():.2f}")
+for k, nm in enumerate(names):
+    print(f"  {nm:14s} {np.median(d[:,k]):9.0f} {d[:,k].mean():9.0f} {d[:,k].max():9.0f}")
+tot = c[:, 9] - c[:, 0]
+print(f"  total          {np.median(tot):9.0f} {tot.mean():9.0f} {tot.max():9.0f}")
+print(f"  kernel span (max end - min start) {c[:,9].max()-c[:,0].min():.0f} cycles; start spread {c[:,0].max()-c[:,0].min():.0f}")
+sel = it > 0
+if sel.any():
+    print(f"  active-set cycles per iteration (blocks with it>0): {np.median(d[sel,7]/it[sel]):.0f}")
