@@ -16,6 +16,7 @@
 #include "qmpc_device.h"
 
 extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
+extern "C" hipError_t qmpc_prepare(void);
 
 struct qmpc_ctx {
   int device = 0;
@@ -30,7 +31,7 @@ struct qmpc_ctx {
   double tol = 1e-9;
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
   int* d_lists = nullptr;      // [2][max_batch] robot ids for classes 2 and 3
-  int* d_counts = nullptr;     // [2]
+  int* d_counts = nullptr;     // [4]: list counts (classes 2,3) and exit tickets; self-re-arming
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
   long long* dbg_clk = nullptr;
@@ -84,7 +85,9 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   const size_t H = (size_t)max_horizon;
   hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
   if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 2 * (size_t)max_batch);
-  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 2);
+  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 4);
+  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 4);
+  if (e == hipSuccess) e = qmpc_prepare();
   if (e != hipSuccess) {
     qmpc_destroy(c);
     return QMPC_ERR_DEVICE;
@@ -218,25 +221,27 @@ int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outpu
   // size classes: n_r = 3 * stance foot-steps <= 64 / 128 / 192
   const int nmax = 12 * h;
   const int nclass = nmax <= 64 ? 1 : (nmax <= 128 ? 2 : 3);
-  if (nclass > 1) HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * 2, stream));
   int* list2 = c->d_lists;
   int* list3 = c->d_lists + c->max_batch;
-  // class 1: one workgroup per robot
-  P.list = nullptr; P.count = nullptr;
+  int* cnt2 = c->d_counts;
+  int* cnt3 = c->d_counts + 1;
+  // class 1: one workgroup per robot; larger robots are appended to list2
+  P.list = nullptr; P.count = nullptr; P.done = nullptr;
   P.next_list = nclass > 1 ? list2 : nullptr;
-  P.next_count = nclass > 1 ? c->d_counts : nullptr;
+  P.next_count = nclass > 1 ? cnt2 : nullptr;
   HIP_TRY(c, qmpc_launch(1, &P, batch, stream));
-  const int pgrid = batch < 1024 ? batch : 1024;
+  // classes 2, 3: persistent stride over the deferred lists (usually empty)
+  const int pgrid = batch < 512 ? batch : 512;
   if (nclass > 1) {
-    P.list = list2; P.count = c->d_counts;
+    P.list = list2; P.count = cnt2; P.done = c->d_counts + 2;
     P.next_list = nclass > 2 ? list3 : nullptr;
-    P.next_count = nclass > 2 ? c->d_counts + 1 : nullptr;
+    P.next_count = nclass > 2 ? cnt3 : nullptr;
     HIP_TRY(c, qmpc_launch(2, &P, pgrid, stream));
   }
   if (nclass > 2) {
-    P.list = list3; P.count = c->d_counts + 1;
+    P.list = list3; P.count = cnt3; P.done = c->d_counts + 3;
     P.next_list = nullptr; P.next_count = nullptr;
-    HIP_TRY(c, qmpc_launch(3, &P, pgrid, stream));
+    HIP_TRY(c, qmpc_launch(3, &P, pgrid < 256 ? pgrid : 256, stream));
   }
   return QMPC_OK;
 }

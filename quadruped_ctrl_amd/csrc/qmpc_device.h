@@ -48,7 +48,8 @@ struct QmpcParams {
   double tol;
   // work lists: robots handed from one size class to the next
   const int* list;   // nullptr: robot = blockIdx.x
-  const int* count;
+  int* count;        // entries in `list`; re-armed to 0 by the last workgroup
+  int* done;         // workgroup exit ticket for that re-arming
   int* next_list;    // nullptr: no larger class available
   int* next_count;
   // debug dump (nullptr = off)

@@ -5,31 +5,118 @@
 // replacing src/MPC_Ctrl/SolverMPC.cpp:296-639 (solve_mpc) of the reference,
 // which runs it for ONE robot on one CPU core through Eigen + qpOASES.
 //
-// Design (DESIGN.md has the derivations):
+// Design (DESIGN.md has the derivations and measurements):
 //   * one workgroup per robot, NT = 256*RB threads, RB in {1,2,3} selected by
 //     the reduced problem size n_r = 3 * (#stance foot-steps) <= 64*RB.
 //   * the n_r x n_r Hessian lives in REGISTERS for the whole solve: thread
 //     (row i, column group c) owns H[i][c*CW .. c*CW+CW-1].  LDS only carries
-//     vectors (pivot columns, matvec operands) and the small working-set
-//     inverse; per robot HBM traffic is the 728 B record in and 48 B out.
-//   * assembly exploits A_ct^3 = 0 (SolverMPC.cpp:235-254):
-//       qH = 2 sum_pq C_pq (x) (B_p^T W B_q) + 2 alpha I
-//     with batch-constant h x h tables C_pq -- no 13h x 12h B_qp is ever
-//     formed (the reference multiplies it densely, SolverMPC.cpp:395).
-//   * inversion by n_r symmetric Gauss-Jordan sweeps (one barrier each), then a
-//     Goldfarb-Idnani dual active-set on the explicit inverse; swing feet are
-//     eliminated up front exactly like SolverMPC.cpp:441-525.
+//     vectors (pivot columns, mat-vec operands) and the small working-set
+//     state; per robot HBM traffic is the 728 B record in and 48 B out.
+//   * assembly exploits A_ct^3 = 0 (SolverMPC.cpp:235-254): with
+//     B0 = B, B1 = A B, B2 = A^2 B and batch-constant h x h tables C_pq,
+//       qH = 2 sum_pq C_pq (x) (B_p^T W B_q) + 2 alpha I,
+//     and every B_p^T W B_q has a closed form in the 3x3 blocks
+//     M_b = I_w^-1 [r_b]x, N_b = R_yaw^T M_b -- no 13h x 12h B_qp is ever formed
+//     (the reference multiplies it densely, SolverMPC.cpp:395).
+//   * inversion by n_r symmetric Gauss-Jordan sweeps, software-pipelined so the
+//     next pivot column is published before the rank-1 update of the current
+//     one is finished (one barrier per pivot); then a Goldfarb-Idnani dual
+//     active-set on the explicit inverse, run by wave 0 out of registers
+//     (lane = stance foot-step / working-set slot).  Swing feet are eliminated
+//     up front exactly like SolverMPC.cpp:441-525.
 //   * fp64 throughout the solve (the reference hands fp32-assembled data to a
 //     double-precision qpOASES; fp64 assembly removes the fp32 rounding noise
 //     instead of adding a second, uncorrelated copy of it).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "qmpc_device.h"
 
 namespace {
 
 constexpr int WAVE = 64;
+
+// ----------------------------------------------------------------- wave helpers
+// DPP control words (gfx9): row_shr:n = 0x110+n, row_bcast:15 = 0x142,
+// row_bcast:31 = 0x143.  After the six steps lane 63 holds the reduction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// max over the 64 lanes of a wave, result uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  unsigned t;
+  t = dpp_u32<0x111, 0xf>(0u, v); v = v > t ? v : t;
+  t = dpp_u32<0x112, 0xf>(0u, v); v = v > t ? v : t;
+  t = dpp_u32<0x114, 0xf>(0u, v); v = v > t ? v : t;
+  t = dpp_u32<0x118, 0xf>(0u, v); v = v > t ? v : t;
+  t = dpp_u32<0x142, 0xa>(0u, v); v = v > t ? v : t;
+  t = dpp_u32<0x143, 0xc>(0u, v); v = v > t ? v : t;
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// min over the wave of NON-NEGATIVE doubles (bit pattern order == value order)
+__device__ __forceinline__ double wave_min_pos_f64(double x) {
+  unsigned long long v = (unsigned long long)__double_as_longlong(x);
+  const unsigned long long ident = ~0ull;
+#define QMPC_MIN_STEP(CTRL, RM)                                                          \
+  {                                                                                      \
+    const unsigned lo = dpp_u32<CTRL, RM>((unsigned)ident, (unsigned)v);                 \
+    const unsigned hi = dpp_u32<CTRL, RM>((unsigned)(ident >> 32), (unsigned)(v >> 32)); \
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;                    \
+    v = o < v ? o : v;                                                                   \
+  }
+  QMPC_MIN_STEP(0x111, 0xf)
+  QMPC_MIN_STEP(0x112, 0xf)
+  QMPC_MIN_STEP(0x114, 0xf)
+  QMPC_MIN_STEP(0x118, 0xf)
+  QMPC_MIN_STEP(0x142, 0xa)
+  QMPC_MIN_STEP(0x143, 0xc)
+#undef QMPC_MIN_STEP
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// element q (uniform) of a small per-lane register array without dynamic indexing
+template <int KW, typename T>
+__device__ __forceinline__ T pick(const T (&arr)[KW], int q) {
+  T v = arr[0];
+#pragma unroll
+  for (int k = 1; k < KW; ++k) v = (q == k) ? arr[k] : v;
+  return v;
+}
+// 1/d to full double precision: v_rcp_f64 seed + two Newton steps
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  return x;
+}
+
+// compile-time loop: f(integral_constant<int, R>) for R = 0 .. N-1, so that
+// register-array indices derived from R are constant expressions
+template <int R, int N>
+struct StaticFor {
+  template <class F>
+  static __device__ __forceinline__ void run(F&& f) {
+    f(std::integral_constant<int, R>{});
+    StaticFor<R + 1, N>::run(f);
+  }
+};
+template <int N>
+struct StaticFor<N, N> {
+  template <class F>
+  static __device__ __forceinline__ void run(F&&) {}
+};
 
 __device__ __forceinline__ int sym_idx(int a, int b) {
   const int hi = a > b ? a : b, lo = a > b ? b : a;
@@ -42,100 +129,95 @@ __device__ __forceinline__ int sym_idx(int a, int b) {
 //   ty 4: -fz >= -fmax_k
 // (fmat / U_b of SolverMPC.cpp:352-378; the BIG_NUMBER uppers can never be
 //  active and fz >= 0 is implied by rows 0+1, so neither is instantiated.)
-struct Con {
-  int j1, j2;
-  double a1, a2, rhs, inv_norm;
-};
-__device__ __forceinline__ Con make_con(int e, double mi, double inv_fr_norm,
-                                        const double* fmaxk) {
-  Con c;
+// As a sparse row c = a1 e_{j1} + a2 e_{j2}:
+__device__ __forceinline__ void con_coefs(int e, double mi, int& j1, int& j2, double& a1, double& a2) {
   const int slot = e / 5, ty = e - 5 * slot, j0 = 3 * slot;
-  c.j2 = j0 + 2;
+  j2 = j0 + 2;
   if (ty < 4) {
-    c.j1 = j0 + (ty >> 1);
-    c.a1 = (ty & 1) ? -mi : mi;
-    c.a2 = 1.0;
-    c.rhs = 0.0;
-    c.inv_norm = inv_fr_norm;
+    j1 = j0 + (ty >> 1);
+    a1 = (ty & 1) ? -mi : mi;
+    a2 = 1.0;
   } else {
-    c.j1 = j0 + 2;
-    c.a1 = -1.0;
-    c.a2 = 0.0;
-    c.rhs = -fmaxk[slot];
-    c.inv_norm = 1.0;
+    j1 = j0 + 2;
+    a1 = -1.0;
+    a2 = 0.0;
   }
-  return c;
 }
 
 template <int RB>
-struct Smem {
+struct Cfg {
   static constexpr int NP = 64 * RB;
-  static constexpr int KMAX = (RB == 1) ? 64 : 96;
+  static constexpr int CW = 16 * RB;
+  static constexpr int NT = 256 * RB;
+  static constexpr int KMAX = (RB == 1) ? 64 : (RB == 2 ? 96 : 128);  // working-set slots
+  static constexpr int KW = (KMAX + 63) / 64;                         // slots per engine lane
+  static constexpr int MCAP = (RB == 1) ? 24 : (RB == 2 ? 16 : 8);    // rows of H^-1 C_W kept in LDS
   static constexpr int NS = KMAX * (KMAX + 1) / 2;
+};
+
+template <int RB>
+struct Smem {
+  using C = Cfg<RB>;
   // ---- live for the whole solve
-  alignas(16) double colbuf[2][NP + 2];
-  double x[NP];
-  double g[NP];
+  QmpcParams par;  // kernel parameters parked in LDS (keeps ~45 uniforms out of SGPRs)
+  alignas(16) double colbuf[2][C::NP + 2];
+  double g[C::NP];
   double fmaxk[64];
   unsigned char sidx[64];
-  unsigned char actf[320];
-  unsigned char slotOf[320];
-  int nst, state, status, iters, khw, p;
-  int cj1, cj2;
-  double ca1, ca2, lp;
-  // kernel parameters, parked in LDS so that 45 uniform values do not stay
-  // live in SGPRs across the whole solve (they were being spilled to scratch)
-  QmpcParams par;
+  int nst, state, status, p_e;
   // ---- phase-local storage
   union U {
     struct Asm {  // linearisation + assembly
-      double A[169];
-      double B[3][156];
-      double W[13], x0[13], Ax[13], AAx[13];
-      double E[9][144];
-      double e[16 * 13];
-      double s[3][16 * 13];
-      double Rt[9], Iinv[9];
-      double ct0[256], ct4[256];  // C_00 (tau) and C_11 (sigma), h x h
+      double Mb[4][9];  // M_b = I_world^-1 [r_b]x                 (B0 rows 6..8)
+      double Nb[4][9];  // N_b = R_yaw^T M_b                       (B1 rows 0..2)
+      double W[12];
+      double coef[3 * 16];
+      double ct0[256], ct4[256];            // C_00 (tau), C_11 (sigma)
+      double ct1[256], ct5[256], ct8[256];  // C_01, C_12, C_22 (x_drag != 0 only)
+      double E00[144], E11[144];
+      double e[16 * 12];
+      double s[3][16 * 12];
     } a;
     struct Slv {  // active-set solve
-      double Sinv[NS];
-      alignas(16) double y[NP];
-      double part[4][NP];
-      double rowA[NP], rowB[NP], hc[NP], z[NP];
-      double lam[KMAX], r[KMAX], d[KMAX];
-      int wcid[KMAX];
+      double Sinv[C::NS];
+      double M[C::MCAP][C::NP];
+      alignas(16) double y[C::NP];
+      double part[4][C::NP];
+      double rowA[C::NP], rowB[C::NP];
     } b;
   } u;
 };
 
-enum { ST_NEXT = 0, ST_INNER = 1, ST_DONE = 2 };
+// block-wide state word written by the engine wave
+enum { ST_NEXT = 0, ST_INNER_FAST = 1, ST_INNER_MATVEC = 2, ST_DONE = 3 };
 
-// phase timestamps (test/profiling hook; P.dbg_clk == nullptr in production)
-#define QMPC_TICK(k)                                                        \
-  do {                                                                     \
-    if (P.dbg_clk && tid == 0) P.dbg_clk[(size_t)rid * 16 + (k)] = clock64(); \
+// phase timestamps (profiling hook; dbg_clk == nullptr in production)
+#define QMPC_TICK(k)                                   \
+  do {                                                 \
+    if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); \
   } while (0)
 
 template <int RB>
-__device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
-  constexpr int NP = 64 * RB, CW = 16 * RB, NT = 256 * RB;
-  constexpr int KMAX = Smem<RB>::KMAX;
+__device__ void solve_one(const int rid, Smem<RB>& S) {
+  using C = Cfg<RB>;
+  constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, MCAP = C::MCAP;
+  const QmpcParams& P = S.par;
   const int tid = threadIdx.x;
-  const int i = tid % NP;   // matrix row owned by this thread
-  const int c = tid / NP;   // column group (0..3): columns c*CW .. c*CW+CW-1
+  const int lane = tid & (WAVE - 1);
+  const int i = tid % NP;  // matrix row owned by this thread
+  const int c = tid / NP;  // column group (0..3): columns c*CW .. c*CW+CW-1
   const int h = P.horizon;
-  const int nfs = 4 * h;    // foot-steps in the horizon (<= 64)
-
+  const int nfs = 4 * h;   // foot-steps in the horizon (<= 64)
+  long long* dbg_clk = P.dbg_clk ? P.dbg_clk + (size_t)rid * 16 : nullptr;
   QMPC_TICK(0);
-  // ------------------------------------------------------------ phase 0a
+
+  // ------------------------------------------------------------ stage 0
   // contact table -> compact stance list (SolverMPC.cpp:441-469 finds the same
-  // set by scanning for ub ~ 0 rows).
+  // set by scanning for ub ~ 0 rows); plus everything that needs no LDS input.
   if (tid < WAVE) {
     float fm = 0.f;
-    if (tid < nfs)
-      fm = (float)P.gait[(size_t)rid * nfs + tid] * (float)P.f_max;  // :361
-    const bool st = !(fm < 0.01f && fm > -.01f);                      // :64-67
+    if (tid < nfs) fm = (float)P.gait[(size_t)rid * nfs + tid] * (float)P.f_max;  // :361
+    const bool st = !(fm < 0.01f && fm > -.01f);                                   // :64-67
     const unsigned long long mask = __ballot(st);
     const int pos = __popcll(mask & ((1ull << tid) - 1ull));
     if (st) {
@@ -145,10 +227,101 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
     if (tid == 0) {
       S.nst = __popcll(mask);
       S.status = 0;
-      S.iters = 0;
     }
   }
-  __syncthreads();
+  if (P.soln)  // q_soln is zero on swing feet (SolverMPC.cpp:545-551)
+    for (int k = tid; k < 12 * h; k += NT) P.soln[(size_t)rid * 12 * h + k] = 0.0;
+
+  auto& Aa = S.u.a;
+  const double x_drag = (double)P.x_drag[(size_t)rid * P.x_drag_stride];
+  const bool drag = (x_drag != 0.0);
+  const double inv_m = 1.0 / P.mass;
+  {
+    // yaw rotation (RobotState.cpp:30-35); float transcendentals like the reference
+    float syf, cyf;
+    sincosf(P.yaw[rid], &syf, &cyf);
+    const double cy = cyf, sy = syf;
+    if (tid < 72) {
+      // M_b = I_w^-1 [r_b]x with I_w^-1 = R diag(1/I) R^T (closed form of
+      // I_world.inverse(), SolverMPC.cpp:319,:247), N_b = R^T M_b.
+      // Thread (b, l, a): t = 9b + 3l + a.
+      const int t = tid % 36, b = t / 9, l = (t % 9) / 3, ax = t % 3;
+      const double ix = 1.0 / P.ibody[0], iy = 1.0 / P.ibody[1], iz = 1.0 / P.ibody[2];
+      const double I00 = cy * cy * ix + sy * sy * iy, I01 = cy * sy * (ix - iy),
+                   I11 = sy * sy * ix + cy * cy * iy;
+      const float* r = P.r + (size_t)rid * 12;  // r_feet(axis, foot) = r[axis*4 + foot], RobotState.cpp:25-27
+      const double rx = r[0 * 4 + b], ry = r[1 * 4 + b], rz = r[2 * 4 + b];
+      // column ax of [r]x  (cross_mat, SolverMPC.cpp:226-233)
+      const double cm0 = (ax == 0) ? 0.0 : (ax == 1 ? -rz : ry);
+      const double cm1 = (ax == 0) ? rz : (ax == 1 ? 0.0 : -rx);
+      const double cm2 = (ax == 0) ? -ry : (ax == 1 ? rx : 0.0);
+      const double m0 = I00 * cm0 + I01 * cm1;  // M_b[0][ax]
+      const double m1 = I01 * cm0 + I11 * cm1;  // M_b[1][ax]
+      const double m2 = iz * cm2;               // M_b[2][ax]
+      if (tid < 36) {
+        Aa.Mb[b][3 * l + ax] = (l == 0) ? m0 : (l == 1 ? m1 : m2);
+      } else {
+        // R^T = [[c, s, 0], [-s, c, 0], [0, 0, 1]]   (A(0:3,6:9), SolverMPC.cpp:244)
+        Aa.Nb[b][3 * l + ax] = (l == 0) ? (cy * m0 + sy * m1) : (l == 1 ? (-sy * m0 + cy * m1) : m2);
+      }
+    } else if (tid >= 96 && tid < 96 + 12) {
+      Aa.W[tid - 96] = (double)P.weights[(size_t)rid * P.weights_stride + (tid - 96)];
+    } else if (tid >= 112 && tid < 112 + 3 * 16) {
+      const int k = tid - 112, pp = k / 16, d = k % 16;
+      if (d < h) Aa.coef[pp * 16 + d] = P.coef[pp * h + d];
+    }
+    // weighted tracking error of the free response at step k (k < h):
+    //   e_k = W .* (x0 + A x0 t + A^2 x0 t^2/2 - xd_k),  t = (k+1) dt
+    // ( = S (A_qp x0 - X_d), SolverMPC.cpp:399 ), closed form per state row.
+    for (int idx = tid; idx < 12 * h; idx += NT) {
+      const int k = idx / 12, row = idx - 12 * k;
+      const double t = (double)(k + 1) * P.dt;
+      double val;
+      if (row < 3) {
+        // x0(0..2) = roll, pitch, yaw from the quaternion (SolverMPC.cpp:257-267, :318)
+        const float* q = P.q + (size_t)rid * 4;
+        const float w = q[0], x = q[1], y = q[2], z = q[3];
+        float ang;
+        if (row == 0) {
+          ang = atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z);
+        } else if (row == 1) {
+          double asd = -2. * (double)(x * z - w * y);
+          if (!(asd < .99999)) asd = .99999;
+          ang = asinf((float)asd);
+        } else {
+          ang = atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z);
+        }
+        const float* om = P.w + (size_t)rid * 3;
+        const double o0 = om[0], o1 = om[1], o2 = om[2];
+        const double rate = (row == 0) ? (cy * o0 + sy * o1) : (row == 1 ? (-sy * o0 + cy * o1) : o2);
+        val = (double)ang + rate * t;  // Theta' = R_yaw^T omega
+      } else if (row < 6) {
+        const float* v = P.v + (size_t)rid * 3;
+        val = (double)P.p[(size_t)rid * 3 + (row - 3)] + (double)v[row - 3] * t;
+        if (row == 5) val += 0.5 * (P.gravity + x_drag * (double)v[0]) * t * t;  // A(11,12), A(11,9)
+      } else if (row < 9) {
+        val = (double)P.w[(size_t)rid * 3 + (row - 6)];
+      } else {
+        const float* v = P.v + (size_t)rid * 3;
+        val = (double)v[row - 9];
+        if (row == 11) val += (P.gravity + x_drag * (double)v[0]) * t;
+      }
+      const double wt = (double)P.weights[(size_t)rid * P.weights_stride + row];
+      Aa.e[idx] = wt * (val - (double)P.traj[(size_t)rid * 12 * h + idx]);
+    }
+    const int hh = h * h;
+    for (int idx = tid; idx < hh; idx += NT) {
+      Aa.ct0[idx] = P.ctab[idx];
+      Aa.ct4[idx] = P.ctab[4 * hh + idx];
+      if (drag) {
+        Aa.ct1[idx] = P.ctab[1 * hh + idx];
+        Aa.ct5[idx] = P.ctab[5 * hh + idx];
+        Aa.ct8[idx] = P.ctab[8 * hh + idx];
+      }
+    }
+  }
+  __syncthreads();  // ---- barrier 1
+  QMPC_TICK(1);
   const int nst = S.nst;
   const int n = 3 * nst;
   if (nst == 0 || n > NP) {
@@ -156,8 +329,6 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
     // this instantiation: hand the robot to the next size class.
     if (nst == 0) {
       if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
-      if (P.soln)
-        for (int k = tid; k < 12 * h; k += NT) P.soln[(size_t)rid * 12 * h + k] = 0.0;
       if (tid == 0) {
         P.status[rid] = 0;
         if (P.iters) P.iters[rid] = 0;
@@ -173,334 +344,253 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
     __syncthreads();
     return;
   }
-
-  auto& Aa = S.u.a;
-  const double x_drag = (double)P.x_drag[(size_t)rid * P.x_drag_stride];
   const double alpha = (double)P.alpha[(size_t)rid * P.alpha_stride];
 
-  QMPC_TICK(1);
-  // ------------------------------------------------------------ phase 0b
-  // scalars: yaw rotation, world inertia inverse, x0 (SolverMPC.cpp:315-319,
-  // RobotState.cpp:30-40).  Transcendentals in float like the reference
-  // (cos/sin/atan2/asin on fpt); four waves take one each.
-  if (tid < 169) Aa.A[tid] = 0.0;
-  if (tid < 13) Aa.W[tid] = (tid < 12) ? (double)P.weights[(size_t)rid * P.weights_stride + tid] : 0.0;
-  __syncthreads();
-  {
-    const float* q = P.q + (size_t)rid * 4;
-    if (tid == 0) {
-      float sy, cy;
-      sincosf(P.yaw[rid], &sy, &cy);
-      const double cd = cy, sd = sy;
-      // R_yaw^T (A(0:3,6:9), SolverMPC.cpp:244)
-      const double Rt[9] = {cd, sd, 0, -sd, cd, 0, 0, 0, 1};
-      for (int k = 0; k < 9; ++k) Aa.Rt[k] = Rt[k];
-      // I_world^-1 = R diag(1/I) R^T  (closed form of :247 I_world.inverse())
-      const double ix = 1.0 / P.ibody[0], iy = 1.0 / P.ibody[1], iz = 1.0 / P.ibody[2];
-      Aa.Iinv[0] = cd * cd * ix + sd * sd * iy;
-      Aa.Iinv[1] = cd * sd * (ix - iy);
-      Aa.Iinv[2] = 0;
-      Aa.Iinv[3] = Aa.Iinv[1];
-      Aa.Iinv[4] = sd * sd * ix + cd * cd * iy;
-      Aa.Iinv[5] = 0;
-      Aa.Iinv[6] = 0;
-      Aa.Iinv[7] = 0;
-      Aa.Iinv[8] = iz;
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) Aa.A[a * 13 + 6 + b] = Rt[3 * a + b];
-      Aa.A[3 * 13 + 9] = 1.0;
-      Aa.A[4 * 13 + 10] = 1.0;
-      Aa.A[5 * 13 + 11] = 1.0;
-      Aa.A[11 * 13 + 9] = x_drag;  // :239
-      Aa.A[11 * 13 + 12] = 1.0;    // :243
-      Aa.x0[12] = P.gravity;
-      for (int k = 0; k < 3; ++k) {
-        Aa.x0[3 + k] = (double)P.p[(size_t)rid * 3 + k];
-        Aa.x0[6 + k] = (double)P.w[(size_t)rid * 3 + k];
-        Aa.x0[9 + k] = (double)P.v[(size_t)rid * 3 + k];
-      }
-    } else if (tid == WAVE) {  // roll  (rpy(2), :265)
-      const float w = q[0], x = q[1], y = q[2], z = q[3];
-      Aa.x0[0] = (double)atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z);
-    } else if (tid == 2 * WAVE) {  // pitch (rpy(1), :262-264)
-      const float w = q[0], x = q[1], y = q[2], z = q[3];
-      double asd = -2. * (double)(x * z - w * y);
-      if (!(asd < .99999)) asd = .99999;
-      Aa.x0[1] = (double)asinf((float)asd);
-    } else if (tid == 3 * WAVE) {  // yaw   (rpy(0), :263)
-      const float w = q[0], x = q[1], y = q[2], z = q[3];
-      Aa.x0[2] = (double)atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z);
-    }
-  }
-  __syncthreads();
-
-  QMPC_TICK(2);
-  // ------------------------------------------------------------ phase 0c
-  // B0 = B_ct (SolverMPC.cpp:246-253); free-response pieces A x0, A^2 x0.
-  if (tid < 156) {
-    const int row = tid / 12, col = tid - 12 * row;
-    const int b = col / 3, jj = col - 3 * b;
-    double v = 0.0;
-    if (row >= 6 && row < 9) {
-      const float* r = P.r + (size_t)rid * 12;
-      const double rx = r[0 * 4 + b], ry = r[1 * 4 + b], rz = r[2 * 4 + b];
-      // column jj of [r]x
-      const double cm0 = (jj == 0) ? 0.0 : (jj == 1 ? -rz : ry);
-      const double cm1 = (jj == 0) ? rz : (jj == 1 ? 0.0 : -rx);
-      const double cm2 = (jj == 0) ? -ry : (jj == 1 ? rx : 0.0);
-      const double* I = &Aa.Iinv[3 * (row - 6)];
-      v = I[0] * cm0 + I[1] * cm1 + I[2] * cm2;
-    } else if (row >= 9 && row < 12) {
-      v = (row - 9 == jj) ? 1.0 / P.mass : 0.0;
-    }
-    Aa.B[0][tid] = v;
-  } else if (tid >= 192 && tid < 192 + 13) {
-    const int row = tid - 192;
-    double s = 0.0;
-    for (int k = 0; k < 13; ++k) s += Aa.A[row * 13 + k] * Aa.x0[k];
-    Aa.Ax[row] = s;
-  }
-  __syncthreads();
-  if (tid < 156) {  // B1 = A B0
-    const int row = tid / 12, col = tid - 12 * row;
-    double s = 0.0;
-    for (int k = 0; k < 13; ++k) s += Aa.A[row * 13 + k] * Aa.B[0][k * 12 + col];
-    Aa.B[1][tid] = s;
-  } else if (tid >= 192 && tid < 192 + 13) {
-    const int row = tid - 192;
-    double s = 0.0;
-    for (int k = 0; k < 13; ++k) s += Aa.A[row * 13 + k] * Aa.Ax[k];
-    Aa.AAx[row] = s;
-  }
-  __syncthreads();
-  if (tid < 156) {  // B2 = A B1   (A^3 = 0 ends the series)
-    const int row = tid / 12, col = tid - 12 * row;
-    double s = 0.0;
-    for (int k = 0; k < 13; ++k) s += Aa.A[row * 13 + k] * Aa.B[1][k * 12 + col];
-    Aa.B[2][tid] = s;
-  }
-  // weighted tracking error of the free response at step k (k < h):
-  //   e_k = W .* (x0 + A x0 t + A^2 x0 t^2/2 - xd_k),  t = (k+1) dt
-  // ( = S (A_qp x0 - X_d), SolverMPC.cpp:399 )
-  for (int idx = tid; idx < 13 * h; idx += NT) {
-    const int k = idx / 13, row = idx - 13 * k;
-    const double t = (double)(k + 1) * P.dt;
-    double v = Aa.x0[row] + Aa.Ax[row] * t + Aa.AAx[row] * (0.5 * t * t);
-    if (row < 12) v -= (double)P.traj[(size_t)rid * 12 * h + 12 * k + row];
-    Aa.e[idx] = Aa.W[row] * v;
-  }
-  __syncthreads();
-
-  QMPC_TICK(3);
-  // ------------------------------------------------------------ phase 0d
-  // E_pq = B_p^T W B_q  and  s_p,i = sum_{k>=i} coef_p(k-i) e_k
-  for (int idx = tid; idx < 9 * 144; idx += NT) {
-    const int pq = idx / 144, uv = idx - 144 * pq;
-    const int pp = pq / 3, qq = pq - 3 * pp, u = uv / 12, v = uv - 12 * u;
-    double s = 0.0;
+  // ------------------------------------------------------------ stage 1
+  // E_00 = B0^T W B0, E_11 = B1^T W B1 in closed form, and the weighted sums
+  // s_p[st] = sum_{k>=st} coef_p(k-st) e_k.
+  if (tid < 144) {
+    const int u = tid / 12, v = tid - 12 * u;
+    const int bu = u / 3, au = u - 3 * bu, bv = v / 3, av = v - 3 * bv;
+    double e00 = 0.0, e11 = 0.0;
 #pragma unroll
-    for (int row = 0; row < 12; ++row)
-      s += Aa.W[row] * (Aa.B[pp][row * 12 + u] * Aa.B[qq][row * 12 + v]);  // E_qp = E_pq^T bitwise
-    Aa.E[pq][uv] = s;
+    for (int l = 0; l < 3; ++l) {  // W * (x * y): E[u][v] == E[v][u] bitwise
+      e00 += Aa.W[6 + l] * (Aa.Mb[bu][3 * l + au] * Aa.Mb[bv][3 * l + av]);
+      e11 += Aa.W[l] * (Aa.Nb[bu][3 * l + au] * Aa.Nb[bv][3 * l + av]);
+    }
+    if (au == av) {
+      e00 += Aa.W[9 + au] * (inv_m * inv_m);
+      e11 += Aa.W[3 + au] * (inv_m * inv_m);
+      if (drag && au == 0) e11 += Aa.W[11] * ((x_drag * inv_m) * (x_drag * inv_m));  // B1 row 11
+    }
+    Aa.E00[tid] = e00;
+    Aa.E11[tid] = e11;
   }
-  for (int idx = tid; idx < h * h; idx += NT) {
-    Aa.ct0[idx] = P.ctab[idx];
-    Aa.ct4[idx] = P.ctab[4 * h * h + idx];
-  }
-  for (int idx = tid; idx < 3 * 13 * h; idx += NT) {
-    const int pp = idx / (13 * h), rem = idx - pp * 13 * h;
-    const int st = rem / 13, row = rem - 13 * st;
+  for (int idx = tid; idx < 3 * 12 * h; idx += NT) {
+    const int pp = idx / (12 * h), rem = idx - pp * 12 * h;
+    const int st = rem / 12, row = rem - 12 * st;
     double s = 0.0;
-    for (int k = st; k < h; ++k) s += P.coef[pp * h + (k - st)] * Aa.e[k * 13 + row];
-    Aa.s[pp][st * 13 + row] = s;
+    for (int k = st; k < h; ++k) s += Aa.coef[pp * 16 + (k - st)] * Aa.e[k * 12 + row];
+    Aa.s[pp][rem] = s;
   }
-  __syncthreads();
+  __syncthreads();  // ---- barrier 2
+  QMPC_TICK(2);
 
-  QMPC_TICK(4);
-  // ------------------------------------------------------------ phase 1
-  // gradient g_red and Hessian rows straight into registers.
-  if (tid < n) {
-    const int ki = S.sidx[tid / 3], ax = tid % 3;
-    const int st = ki >> 2, u = 3 * (ki & 3) + ax;
-    double s = 0.0;
-    for (int pp = 0; pp < 3; ++pp)
-      for (int row = 0; row < 12; ++row)
-        s += Aa.B[pp][row * 12 + u] * Aa.s[pp][st * 13 + row];
-    S.g[tid] = 2.0 * s;
-  } else if (tid < NP) {
-    S.g[tid] = 0.0;
+  // ------------------------------------------------------------ stage 2
+  // gradient g_red -> LDS, Hessian rows straight into registers.
+  if (tid < NP) {
+    double gv = 0.0;
+    if (tid < n) {
+      const int ki = S.sidx[tid / 3], ax = tid % 3;
+      const int st = ki >> 2, b = ki & 3;
+      const double* s0 = &Aa.s[0][st * 12];
+      const double* s1 = &Aa.s[1][st * 12];
+      // g = 2 sum_p B_p^T s_p :  B0 rows 6..8 = M_b, 9..11 = I/m ;
+      //                          B1 rows 0..2 = N_b, 3..5 = I/m, row 11 = x_drag/m on fx ;
+      //                          B2 row 5 = x_drag/m on fx
+      double acc = s0[9 + ax] * inv_m + s1[3 + ax] * inv_m;
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+        acc += Aa.Mb[b][3 * l + ax] * s0[6 + l] + Aa.Nb[b][3 * l + ax] * s1[l];
+      if (drag && ax == 0) acc += (x_drag * inv_m) * (s1[11] + Aa.s[2][st * 12 + 5]);
+      gv = 2.0 * acc;
+    }
+    S.g[tid] = gv;
   }
 
   double a[CW];
   {
-    int si = 0, u = 0;
+    int si = 0, u = 0, ai = 0;
     const bool rowok = i < n;
     if (rowok) {
       const int ki = S.sidx[i / 3];
+      ai = i % 3;
       si = ki >> 2;
-      u = 3 * (ki & 3) + (i % 3);
+      u = 3 * (ki & 3) + ai;
     }
-    const bool drag = (x_drag != 0.0);
-    const int hh = h * h;
-    if (!drag) {
-      // x_drag == 0: only (p,q) = (0,0) and (1,1) survive:
-      //   H = 2 (tau (x) E_00 + sigma (x) E_11 + alpha I)
+    const double dm2 = x_drag * inv_m * inv_m;
+    // column j = c*CW + jj walks stance slots; (slot, axis) advance incrementally
+    int cslot = (c * CW) / 3, cax = (c * CW) % 3;
 #pragma unroll
-      for (int jj = 0; jj < CW; ++jj) {
-        const int j = c * CW + jj;
-        double val = (i == j) ? 1.0 : 0.0;  // identity padding
-        if (rowok && j < n) {
-          const int kj = S.sidx[j / 3];
-          const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + (j % 3);
-          double acc = Aa.ct0[cidx] * Aa.E[0][eidx] + Aa.ct4[cidx] * Aa.E[4][eidx];
-          if (i == j) acc += alpha;
-          val = 2.0 * acc;  // qH = 2 (B^T S B + alpha I), SolverMPC.cpp:395
+    for (int jj = 0; jj < CW; ++jj) {
+      const int j = c * CW + jj;
+      double val = (i == j) ? 1.0 : 0.0;  // identity padding
+      if (rowok && j < n) {
+        const int kj = S.sidx[cslot];
+        const int sj = kj >> 2, cidx = si * h + sj, eidx = u * 12 + 3 * (kj & 3) + cax;
+        // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
+        double acc = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
+        if (drag) {
+          // E_01 / E_12 couple (z of foot-step i, x of foot-step j); E_10 / E_21 the
+          // transposed pair (C_qp[i][j] == C_pq[j][i]); E_22 couples x with x.
+          const int tidx = sj * h + si;
+          if (ai == 2 && cax == 0) acc += (Aa.ct1[cidx] * Aa.W[11] + Aa.ct5[cidx] * Aa.W[5]) * dm2;
+          if (ai == 0 && cax == 2) acc += (Aa.ct1[tidx] * Aa.W[11] + Aa.ct5[tidx] * Aa.W[5]) * dm2;
+          if (ai == 0 && cax == 0) acc += Aa.ct8[cidx] * Aa.W[5] * (x_drag * dm2);
         }
-        a[jj] = val;
-        if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if (i == j) acc += alpha;
+        val = 2.0 * acc;
       }
-    } else {
-#pragma unroll
-      for (int jj = 0; jj < CW; ++jj) {
-        const int j = c * CW + jj;
-        double val = (i == j) ? 1.0 : 0.0;
-        if (rowok && j < n) {
-          const int kj = S.sidx[j / 3];
-          const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + (j % 3);
-          // summed so that H[i][j] == H[j][i] bitwise: (p,q) and (q,p) terms
-          // are paired, and ctab[qp][sj][si] == ctab[pq][si][sj], E_qp = E_pq^T
-          auto term = [&](int pq) { return P.ctab[pq * hh + cidx] * Aa.E[pq][eidx]; };
-          double acc = term(0) + term(4) + term(8);
-          acc += term(1) + term(3);
-          acc += term(2) + term(6);
-          acc += term(5) + term(7);
-          if (i == j) acc += alpha;
-          val = 2.0 * acc;
-        }
-        a[jj] = val;
-        __builtin_amdgcn_sched_barrier(0);
+      a[jj] = val;
+      if (++cax == 3) {
+        cax = 0;
+        ++cslot;
       }
+      if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
     }
   }
   if (P.dbg_H) {
     double* Hd = P.dbg_H + (size_t)rid * QMPC_DBG_LD * QMPC_DBG_LD;
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) Hd[(size_t)i * QMPC_DBG_LD + c * CW + jj] = a[jj];
-    if (tid < NP) P.dbg_g[(size_t)rid * QMPC_DBG_LD + tid] = (tid < n) ? S.g[tid] : 0.0;
+    if (tid < NP) P.dbg_g[(size_t)rid * QMPC_DBG_LD + tid] = S.g[tid];
   }
-  __syncthreads();  // Asm storage dead from here on (g, sidx, fmaxk are not in the union)
+  QMPC_TICK(3);
 
-  QMPC_TICK(5);
-  // ------------------------------------------------------------ phase 2
+  // ------------------------------------------------------------ stage 3
   // n symmetric Gauss-Jordan sweeps: a <- -H^-1, one barrier per pivot.
-  // Pivot column k is owned by column group k / CW in register k % CW; it is
-  // broadcast through a double-buffered LDS vector (row k == column k).
+  // Pivot column k lives in column group k / CW, register k % CW, and is
+  // broadcast through a double-buffered LDS vector (row k == column k by
+  // symmetry).  Pivot row trick: a_kj <- a_kj/d  ==  a_kj - ((d-1)/d) c_j, so the
+  // rank-1 update is one fma per element with no row special-casing.
+  bool notpd = false;
   {
-    bool notpd = false;
+    // software pipeline: the owner updates and publishes column k+1 BEFORE the
+    // rank-1 update for pivot k, so the LDS write latency and most of the
+    // barrier wait overlap that update; the column is then re-read after the
+    // barrier into the same registers.
+    if (c == 0) S.colbuf[0][i] = a[0];
+    __syncthreads();
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-      for (int r = 0; r < CW; ++r) {
+      StaticFor<0, CW>::run([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int rn = (r + 1 < CW) ? r + 1 : 0;
         const int k = kb * CW + r;
         if (k < n) {
-          double* cb = S.colbuf[k & 1];
-          if (c == kb) cb[i] = a[r];
-          __syncthreads();
+          const double* cb = S.colbuf[k & 1];
           double d = cb[k];
+          const double ci = cb[i];
+          double cj[CW];
+#pragma unroll
+          for (int jj = 0; jj < CW; ++jj) cj[jj] = cb[c * CW + jj];
           if (!(d > 1e-300)) {
             notpd = true;
             d = 1e-300;
           }
-          const double dinv = 1.0 / d;
-          const double ci = cb[i];
-          const double f = ci * dinv;
+          const double dinv = fast_rcp(d);
           const bool prow = (i == k);
+          const double f = (prow ? (d - 1.0) : ci) * dinv;
+          // -- next pivot column first
+          const int kbn = (r + 1 < CW) ? kb : kb + 1;
+          const bool own_next = (k + 1 < n) && (c == kbn);
+          if (own_next) {
+            a[rn] = __builtin_fma(-f, cj[rn], a[rn]);
+            S.colbuf[(k + 1) & 1][i] = a[rn];
+          }
+          // -- rank-1 update for pivot k
 #pragma unroll
           for (int jj = 0; jj < CW; ++jj) {
-            const double cj = cb[c * CW + jj];
-            const double upd = __builtin_fma(-f, cj, a[jj]);
-            a[jj] = prow ? cj * dinv : upd;
+            const double upd = __builtin_fma(-f, cj[jj], a[jj]);
+            a[jj] = (jj == rn && own_next) ? a[jj] : upd;
           }
-          if (c == kb) a[r] = prow ? -dinv : f;
+          if (c == kb) a[r] = prow ? -dinv : f;  // column k itself
+          __syncthreads();
         }
-      }
+      });
     }
-    if (notpd && tid == 0) S.status |= QMPC_DEV_ST_NOT_PD;
   }
+  if (notpd && tid == 0) S.status |= QMPC_DEV_ST_NOT_PD;
+  QMPC_TICK(4);
 
   auto& Sb = S.u.b;
-  QMPC_TICK(6);
-  // ------------------------------------------------------------ phase 3
+  // ------------------------------------------------------------ stage 4
   // unconstrained minimiser x = -H^-1 g = a * g   (distributed mat-vec)
   {
     double acc = 0.0;
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) acc = __builtin_fma(a[jj], S.g[c * CW + jj], acc);
+    __syncthreads();  // assembly storage (union) is dead from here on
     Sb.part[c][i] = acc;
-    for (int k = tid; k < KMAX; k += NT) {
-      Sb.wcid[k] = -1;
-      Sb.lam[k] = 0.0;
-      Sb.r[k] = 0.0;
-      Sb.d[k] = 0.0;
-    }
-    for (int k = tid; k < Smem<RB>::NS; k += NT) Sb.Sinv[k] = 0.0;
-    for (int k = tid; k < 320; k += NT) {
-      S.actf[k] = 0;
-      S.slotOf[k] = 0xFF;
-    }
-    if (tid == 0) S.khw = 0;
+    for (int k = tid; k < C::NS; k += NT) Sb.Sinv[k] = 0.0;
   }
   __syncthreads();
-  if (tid < NP) S.x[tid] = Sb.part[0][tid] + Sb.part[1][tid] + Sb.part[2][tid] + Sb.part[3][tid];
-  __syncthreads();
+  QMPC_TICK(5);
 
-  QMPC_TICK(7);
-  // ------------------------------------------------------------ phase 4
+  // ------------------------------------------------------------ stage 5
   // Goldfarb-Idnani dual active set on the explicit inverse.  Wave 0 is the
-  // engine (all small algebra, no block barriers inside a step); the other
-  // waves serve row extractions and mat-vecs of the register-resident -H^-1.
-  const int lane = tid & (WAVE - 1);
+  // engine and keeps its state in registers:
+  //   lane = stance slot sl : x[3sl..3sl+2], working-set membership of its 5 rows
+  //   lane = working-set slot w (+64q): constraint id, multiplier, r_w
+  // The other waves only serve columns of the register-resident -H^-1 (one
+  // ds_write per lane) and, past MCAP working constraints, mat-vecs.
   const bool engine = tid < WAVE;
   const double mi = P.mu_inv;
   const double inv_fr = P.inv_fr_norm;
-  const int ncon = 5 * nst;
+  const double tol = P.tol;
+  const int max_iter = P.max_iter;
 
-  // engine: pick the most violated inactive constraint; publish it or DONE
-  auto select = [&]() {
-    double best = 0.0;
-    int beste = -1;
-    for (int e = lane; e < ncon; e += WAVE) {
-      if (S.actf[e]) continue;
-      const Con cn = make_con(e, mi, inv_fr, S.fmaxk);
-      const double s = (cn.a1 * S.x[cn.j1] + cn.a2 * S.x[cn.j2] - cn.rhs) * cn.inv_norm;
-      if (s < best) {
-        best = s;
-        beste = e;
-      }
-    }
+  double xs[3] = {0.0, 0.0, 0.0};  // engine lane sl: forces of stance slot sl
+  double fmx = 0.0;                // its f_max
+  unsigned amask = 0;              // bit ty: constraint (sl, ty) is in the working set
+  unsigned aslot[5] = {0, 0, 0, 0, 0};  // ... and the working-set slot holding it
+  int wcid[KW];                    // engine lane w: constraint id in slot w + 64 q, -1 = free
+  double lam[KW], rw[KW];
+  int khw = 0;                     // high-water mark of used working-set slots (uniform)
+  int iters = 0;
+  double lp = 0.0;                 // multiplier of the constraint being added
+  // uniform description of the constraint being added
+  int p_e = -1, pj1 = 0, pj2 = 0;
+  double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off);
-      const int oe = __shfl_xor(beste, off);
-      if (ob < best || (ob == best && oe >= 0 && (beste < 0 || oe < beste))) {
-        best = ob;
-        beste = oe;
+  for (int q = 0; q < KW; ++q) {
+    wcid[q] = -1;
+    lam[q] = 0.0;
+    rw[q] = 0.0;
+  }
+  if (engine && lane < nst) {
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const int j = 3 * lane + ax;
+      xs[ax] = Sb.part[0][j] + Sb.part[1][j] + Sb.part[2][j] + Sb.part[3][j];
+    }
+    fmx = S.fmaxk[lane];
+  }
+
+  // engine: pick the most violated inactive constraint (normalised by the row
+  // norm); publish it (state NEXT) or finish (state DONE)
+  auto select = [&]() __attribute__((always_inline)) {
+    unsigned key = 0;
+    if (lane < nst) {
+      const double sv[5] = {(mi * xs[0] + xs[2]) * inv_fr, (-mi * xs[0] + xs[2]) * inv_fr,
+                            (mi * xs[1] + xs[2]) * inv_fr, (-mi * xs[1] + xs[2]) * inv_fr, fmx - xs[2]};
+#pragma unroll
+      for (int ty = 0; ty < 5; ++ty) {
+        if (!((amask >> ty) & 1u) && sv[ty] < -tol) {
+          // more negative -> larger float magnitude -> larger key; low 9 bits = id
+          const unsigned kk = (__float_as_uint((float)(-sv[ty])) & ~0x1FFu) | (unsigned)(5 * lane + ty);
+          key = kk > key ? kk : key;
+        }
       }
     }
-    if (lane == 0) {
-      if (beste < 0 || best >= -P.tol) {
-        S.state = ST_DONE;
-      } else if (S.iters >= P.max_iter) {
+    const unsigned best = wave_max_u32(key);
+    if (best == 0u) {
+      if (lane == 0) S.state = ST_DONE;
+      p_e = -1;
+    } else if (iters >= max_iter) {
+      if (lane == 0) {
         S.status |= QMPC_DEV_ST_MAXITER;
         S.state = ST_DONE;
-      } else {
-        const Con cn = make_con(beste, mi, inv_fr, S.fmaxk);
-        S.p = beste;
-        S.cj1 = cn.j1;
-        S.cj2 = cn.j2;
-        S.ca1 = cn.a1;
-        S.ca2 = cn.a2;
-        S.lp = 0.0;
+      }
+      p_e = -1;
+    } else {
+      p_e = (int)(best & 0x1FFu);
+      con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+      const double fm_p = readlane_f64(fmx, p_e / 5);
+      p_rhs = (p_e % 5 == 4) ? -fm_p : 0.0;
+      lp = 0.0;
+      if (lane == 0) {
+        S.p_e = p_e;
         S.state = ST_NEXT;
       }
     }
@@ -510,110 +600,166 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
   __syncthreads();
 
   while (S.state != ST_DONE) {
-    // --- rows j1, j2 of H^-1 (= -a) out of the registers
+    // --- columns j1, j2 of H^-1 (= -a; row == column by symmetry) out of the
+    //     registers: the owning column group stores one value per lane.
     {
-      const int j1 = S.cj1, j2 = S.cj2;
-      if (i == j1) {
+      int j1, j2;
+      double a1, a2;
+      con_coefs(S.p_e, mi, j1, j2, a1, a2);
+      auto put_col = [&](int j, double* dst) __attribute__((always_inline)) {
+        if (c == j / CW) {
+          const int r = j % CW;  // uniform
+          // select by VALUE: the empty asm keeps LLVM from turning the chain into a
+          // select of addresses + one dynamic load, which would force a[] to scratch
+          double v = a[0];
 #pragma unroll
-        for (int jj = 0; jj < CW; ++jj) Sb.rowA[c * CW + jj] = -a[jj];
-      }
-      if (i == j2) {
-#pragma unroll
-        for (int jj = 0; jj < CW; ++jj) Sb.rowB[c * CW + jj] = -a[jj];
-      }
+          for (int q = 1; q < CW; ++q) {
+            double t = a[q];
+            asm volatile("" : "+v"(t));
+            v = (r == q) ? t : v;
+          }
+          dst[i] = -v;
+        }
+      };
+      put_col(j1, Sb.rowA);
+      if (a2 != 0.0) put_col(j2, Sb.rowB);
     }
     __syncthreads();
+    // hc = H^-1 c_p, slot-major in the engine: lane sl holds hc[3sl..3sl+2]
+    double hcs[3] = {0.0, 0.0, 0.0};
+    double hcn = 0.0;  // c_p^T H^-1 c_p
+    const bool two = (pa2 != 0.0);
+    auto hc_at = [&](int j) __attribute__((always_inline)) { return pa1 * Sb.rowA[j] + (two ? pa2 * Sb.rowB[j] : 0.0); };
     if (engine) {
-      const double a1 = S.ca1, a2 = S.ca2;
-      for (int k = lane; k < NP; k += WAVE) Sb.hc[k] = a1 * Sb.rowA[k] + a2 * Sb.rowB[k];
+      if (lane < nst) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) hcs[ax] = hc_at(3 * lane + ax);
+      }
+      hcn = pa1 * hc_at(pj1) + (two ? pa2 * hc_at(pj2) : 0.0);
     }
     // --- inner loop: one pass per (partial or full) step
     while (true) {
+      double zs[3] = {0.0, 0.0, 0.0};
       if (engine) {
-        __builtin_amdgcn_wave_barrier();
-        const int khw = S.khw;
-        // d = C_W^T H^-1 c_p ; r = S_W^-1 d
-        for (int w = lane; w < khw; w += WAVE) {
-          double dv = 0.0;
-          const int e = Sb.wcid[w];
-          if (e >= 0) {
-            const Con cw = make_con(e, mi, inv_fr, S.fmaxk);
-            dv = cw.a1 * Sb.hc[cw.j1] + cw.a2 * Sb.hc[cw.j2];
-          }
-          Sb.d[w] = dv;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int w = lane; w < khw; w += WAVE) {
-          double rv = 0.0;
-          for (int v = 0; v < khw; ++v) rv = __builtin_fma(Sb.Sinv[sym_idx(w, v)], Sb.d[v], rv);
-          Sb.r[w] = (Sb.wcid[w] >= 0) ? rv : 0.0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // y = c_p - C_W r, gathered per stance slot (no scatter conflicts)
-        for (int k = lane; k < NP; k += WAVE) Sb.y[k] = 0.0;
-        __builtin_amdgcn_wave_barrier();
-        for (int sl = lane; sl < nst; sl += WAVE) {
-          double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-          const int e0 = 5 * sl;
-          int q;
-          q = S.slotOf[e0 + 0]; if (q != 0xFF) { y0 -= mi * Sb.r[q]; y2 -= Sb.r[q]; }
-          q = S.slotOf[e0 + 1]; if (q != 0xFF) { y0 += mi * Sb.r[q]; y2 -= Sb.r[q]; }
-          q = S.slotOf[e0 + 2]; if (q != 0xFF) { y1 -= mi * Sb.r[q]; y2 -= Sb.r[q]; }
-          q = S.slotOf[e0 + 3]; if (q != 0xFF) { y1 += mi * Sb.r[q]; y2 -= Sb.r[q]; }
-          q = S.slotOf[e0 + 4]; if (q != 0xFF) { y2 += Sb.r[q]; }
-          Sb.y[3 * sl + 0] = y0;
-          Sb.y[3 * sl + 1] = y1;
-          Sb.y[3 * sl + 2] = y2;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-          Sb.y[S.cj1] += S.ca1;
-          if (S.ca2 != 0.0) Sb.y[S.cj2] += S.ca2;
-        }
-      }
-      __syncthreads();
-      // --- z = H^-1 y : distributed mat-vec on the register matrix
-      {
-        double acc = 0.0;
+        // d = C_W^T H^-1 c_p (lane = working-set slot), r = S_W^-1 d
+        double dw[KW];
 #pragma unroll
-        for (int jj = 0; jj < CW; ++jj) acc = __builtin_fma(a[jj], Sb.y[c * CW + jj], acc);
-        Sb.part[c][i] = acc;
-      }
-      __syncthreads();
-      if (engine) {
-        for (int k = lane; k < NP; k += WAVE)
-          Sb.z[k] = -(Sb.part[0][k] + Sb.part[1][k] + Sb.part[2][k] + Sb.part[3][k]);
-        __builtin_amdgcn_wave_barrier();
-        const int khw = S.khw;
-        const int j1 = S.cj1, j2 = S.cj2;
-        const double a1 = S.ca1, a2 = S.ca2;
-        const Con cp = make_con(S.p, mi, inv_fr, S.fmaxk);
-        const double delta = a1 * Sb.z[j1] + a2 * Sb.z[j2];
-        const double hcn = a1 * Sb.hc[j1] + a2 * Sb.hc[j2];
-        const double sp = a1 * S.x[j1] + a2 * S.x[j2] - cp.rhs;
-        const bool dep = !(delta > 1e-12 * hcn);
-        const double t2 = dep ? __builtin_inf() : -sp / delta;
-        // t1: largest dual step keeping the working-set multipliers >= 0
-        double t1 = __builtin_inf();
-        int l = -1;
-        for (int w = lane; w < khw; w += WAVE) {
-          const double rv = Sb.r[w];
-          if (Sb.wcid[w] >= 0 && rv > 0.0) {
-            const double q = Sb.lam[w] / rv;
-            if (q < t1) {
-              t1 = q;
-              l = w;
+        for (int q = 0; q < KW; ++q) {
+          dw[q] = 0.0;
+          if (wcid[q] >= 0) {
+            int j1, j2;
+            double a1, a2;
+            con_coefs(wcid[q], mi, j1, j2, a1, a2);
+            dw[q] = a1 * hc_at(j1) + (a2 != 0.0 ? a2 * hc_at(j2) : 0.0);
+          }
+          rw[q] = 0.0;
+        }
+        for (int v = 0; v < khw; ++v) {
+          const double dv = readlane_f64(pick<KW>(dw, v >> 6), v & 63);
+          if (dv != 0.0) {
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+              const int w = lane + 64 * q;
+              if (w < khw) rw[q] = __builtin_fma(Sb.Sinv[sym_idx(w, v)], dv, rw[q]);
             }
           }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const double ot = __shfl_xor(t1, off);
-          const int ol = __shfl_xor(l, off);
-          if (ot < t1 || (ot == t1 && ol >= 0 && (l < 0 || ol < l))) {
-            t1 = ot;
-            l = ol;
+        for (int q = 0; q < KW; ++q)
+          if (wcid[q] < 0) rw[q] = 0.0;
+        const int mode = (khw <= MCAP) ? ST_INNER_FAST : ST_INNER_MATVEC;
+        if (mode == ST_INNER_FAST) {
+          // z = hc - M r  with the rows M[w] = H^-1 c_w kept in LDS
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) zs[ax] = hcs[ax];
+          for (int w = 0; w < khw; ++w) {
+            const double rv = readlane_f64(rw[0], w);  // MCAP <= 64: slot w lives in q = 0
+            if (rv != 0.0 && lane < nst) {
+#pragma unroll
+              for (int ax = 0; ax < 3; ++ax) zs[ax] = __builtin_fma(-rv, Sb.M[w][3 * lane + ax], zs[ax]);
+            }
           }
+        } else {
+          // y = c_p - C_W r, gathered per stance slot, for the distributed mat-vec
+          for (int k = lane; k < NP; k += WAVE) Sb.y[k] = 0.0;
+          double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+          for (int ty = 0; ty < 5; ++ty) {
+            // r of the working-set slot holding (lane, ty), fetched from its owner lane
+            const unsigned sl = aslot[ty];
+            double rv = 0.0;
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+              const double cand = __shfl(rw[q], (int)(sl & 63u));
+              if ((int)(sl >> 6) == q) rv = cand;
+            }
+            if ((amask >> ty) & 1u) {
+              const double sg = (ty & 1) ? -mi : mi;
+              if (ty < 2) y0 -= sg * rv;
+              else if (ty < 4) y1 -= sg * rv;
+              y2 -= (ty < 4) ? rv : -rv;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < nst) {
+            Sb.y[3 * lane + 0] = y0;
+            Sb.y[3 * lane + 1] = y1;
+            Sb.y[3 * lane + 2] = y2;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {
+            Sb.y[pj1] += pa1;
+            if (two) Sb.y[pj2] += pa2;
+          }
+        }
+        if (lane == 0) S.state = mode;
+      }
+      __syncthreads();
+      if (S.state == ST_INNER_MATVEC) {
+        // --- z = H^-1 y : distributed mat-vec on the register matrix
+        double acc = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) acc = __builtin_fma(a[jj], Sb.y[c * CW + jj], acc);
+        Sb.part[c][i] = acc;
+        __syncthreads();
+        if (engine && lane < nst) {
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const int j = 3 * lane + ax;
+            zs[ax] = -(Sb.part[0][j] + Sb.part[1][j] + Sb.part[2][j] + Sb.part[3][j]);
+          }
+        }
+      }
+      if (engine) {
+        // delta = c_p^T z, current violation of p, step lengths
+        const int psl = p_e / 5, pty = p_e - 5 * psl;
+        const int ax1 = pj1 - 3 * psl;  // axis of the first coefficient (2 for the f_max row)
+        const double dloc = pa1 * (ax1 == 0 ? zs[0] : (ax1 == 1 ? zs[1] : zs[2])) + pa2 * zs[2];
+        const double sloc = pa1 * (ax1 == 0 ? xs[0] : (ax1 == 1 ? xs[1] : xs[2])) + pa2 * xs[2] - p_rhs;
+        const double delta = readlane_f64(dloc, psl);
+        const double sp = readlane_f64(sloc, psl);
+        const bool dep = !(delta > 1e-12 * hcn);
+        const double t2 = dep ? __builtin_inf() : -sp / delta;
+        // t1: largest dual step keeping the working-set multipliers >= 0
+        double ratio = __builtin_inf();
+        int lq = 0;
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+          if (wcid[q] >= 0 && rw[q] > 0.0) {
+            double qv = lam[q] / rw[q];
+            qv = qv > 0.0 ? qv : 0.0;
+            if (qv < ratio) {
+              ratio = qv;
+              lq = q;
+            }
+          }
+        }
+        const double t1 = wave_min_pos_f64(ratio);
+        int l = -1;
+        if (t1 < __builtin_inf()) {
+          const unsigned long long m = __ballot(ratio == t1);
+          const int ll = __ffsll((long long)m) - 1;
+          l = ll + 64 * __builtin_amdgcn_readlane(lq, ll);
         }
         const double t = (t2 <= t1) ? t2 : t1;
         if (!(t < __builtin_inf())) {
@@ -622,131 +768,193 @@ __device__ void solve_one(const QmpcParams& P, const int rid, Smem<RB>& S) {
             S.state = ST_DONE;
           }
         } else {
-          if (!dep)
-            for (int k = lane; k < n; k += WAVE) S.x[k] = __builtin_fma(t, Sb.z[k], S.x[k]);
-          for (int w = lane; w < khw; w += WAVE) Sb.lam[w] -= t * Sb.r[w];
-          if (lane == 0) {
-            S.lp += t;
-            S.iters += 1;
+          if (!dep) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) xs[ax] = __builtin_fma(t, zs[ax], xs[ax]);
           }
-          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
+          lp += t;
+          iters += 1;
           if (t2 <= t1) {
             // full step: constraint p joins the working set in a free slot
-            int q = -1;
-            for (int base = 0; base < KMAX && q < 0; base += WAVE) {
-              const int w = base + lane;
-              const bool fr = (w < KMAX) && (Sb.wcid[w] < 0);
+            int qslot = -1;
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+              const bool fr = (lane + 64 * q < KMAX) && (wcid[q] < 0);
               const unsigned long long m = __ballot(fr);
-              if (m) q = base + __ffsll((long long)m) - 1;
+              if (qslot < 0 && m) qslot = 64 * q + __ffsll((long long)m) - 1;
             }
-            if (q < 0) {
+            if (qslot < 0) {
               if (lane == 0) {
                 S.status |= QMPC_DEV_ST_WS_FULL;
                 S.state = ST_DONE;
               }
             } else {
-              const int kn = (q + 1 > khw) ? q + 1 : khw;
+              const int kn = (qslot + 1 > khw) ? qslot + 1 : khw;
               const double dinv = 1.0 / delta;
-              // bordered-inverse update of S_W^-1 (inactive slots have r = 0)
-              for (int hi = 0; hi < kn; ++hi)
-                for (int lo = lane; lo <= hi; lo += WAVE) {
-                  const int idx = hi * (hi + 1) / 2 + lo;
-                  double v;
-                  if (hi == q && lo == q) v = dinv;
-                  else if (hi == q) v = -Sb.r[lo] * dinv;
-                  else if (lo == q) v = -Sb.r[hi] * dinv;
-                  else v = __builtin_fma(Sb.r[hi] * dinv, Sb.r[lo], Sb.Sinv[idx]);
-                  Sb.Sinv[idx] = v;
+              // bordered-inverse update of S_W^-1 (free slots have r = 0):
+              //   S[a][b] += r_a r_b / delta ; S[q][a] = -r_a / delta ; S[q][q] = 1/delta
+              for (int hi = 0; hi < kn; ++hi) {
+                const double rhi = readlane_f64(pick<KW>(rw, hi >> 6), hi & 63);
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                  const int lo = lane + 64 * q;
+                  if (lo <= hi) {
+                    const int idx = hi * (hi + 1) / 2 + lo;
+                    double v;
+                    if (hi == qslot && lo == qslot) v = dinv;
+                    else if (hi == qslot) v = -rw[q] * dinv;
+                    else if (lo == qslot) v = -rhi * dinv;
+                    else v = __builtin_fma(rhi * dinv, rw[q], Sb.Sinv[idx]);
+                    Sb.Sinv[idx] = v;
+                  }
                 }
-              if (lane == 0) {
-                Sb.wcid[q] = S.p;
-                Sb.lam[q] = S.lp;
-                Sb.r[q] = 0.0;
-                S.slotOf[S.p] = (unsigned char)q;
-                S.actf[S.p] = 1;
-                S.khw = kn;
               }
-              __builtin_amdgcn_wave_barrier();
+              if (qslot < MCAP && lane < nst) {
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) Sb.M[qslot][3 * lane + ax] = hcs[ax];
+              }
+#pragma unroll
+              for (int q = 0; q < KW; ++q)
+                if (lane + 64 * q == qslot) {
+                  wcid[q] = p_e;
+                  lam[q] = lp;
+                  rw[q] = 0.0;
+                }
+              if (lane == psl) {
+                amask |= (1u << pty);
+#pragma unroll
+                for (int ty = 0; ty < 5; ++ty)
+                  if (ty == pty) aslot[ty] = (unsigned)qslot;
+              }
+              khw = kn;
               select();  // next violated constraint, or DONE
             }
           } else {
-            // partial step: multiplier of slot l hit zero -> drop it
-            const double sll = Sb.Sinv[sym_idx(l, l)];
-            const double il = 1.0 / sll;
-            // S' = S - S[:,l] S[l,:] / S[l,l] on the other slots; row/col l is
-            // only read here and zeroed afterwards, so in place is safe.
-            for (int hi = 0; hi < khw; ++hi)
-              for (int lo = lane; lo <= hi; lo += WAVE)
-                if (hi != l && lo != l) {
+            // partial step: the multiplier of slot l hit zero -> drop it.
+            //   S' = S - S[:,l] S[l,:] / S[l,l] on the other slots; row/col l is
+            //   only read here and zeroed afterwards, so in place is safe.
+            const double il = 1.0 / Sb.Sinv[sym_idx(l, l)];
+            for (int hi = 0; hi < khw; ++hi) {
+              if (hi == l) continue;
+              const double shl = Sb.Sinv[sym_idx(hi, l)] * il;
+#pragma unroll
+              for (int q = 0; q < KW; ++q) {
+                const int lo = lane + 64 * q;
+                if (lo <= hi && lo != l) {
                   const int idx = hi * (hi + 1) / 2 + lo;
-                  Sb.Sinv[idx] = __builtin_fma(-Sb.Sinv[sym_idx(hi, l)] * il, Sb.Sinv[sym_idx(l, lo)], Sb.Sinv[idx]);
+                  Sb.Sinv[idx] = __builtin_fma(-shl, Sb.Sinv[sym_idx(l, lo)], Sb.Sinv[idx]);
                 }
-            __builtin_amdgcn_wave_barrier();
-            for (int w = lane; w < khw; w += WAVE) Sb.Sinv[sym_idx(w, l)] = 0.0;
-            if (lane == 0) {
-              const int e = Sb.wcid[l];
-              Sb.wcid[l] = -1;
-              Sb.lam[l] = 0.0;
-              Sb.r[l] = 0.0;
-              S.slotOf[e] = 0xFF;
-              S.actf[e] = 0;
-              S.state = ST_INNER;
+              }
             }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < KW; ++q) {
+              const int w = lane + 64 * q;
+              if (w < khw) Sb.Sinv[sym_idx(w, l)] = 0.0;
+            }
+            // the dropped constraint leaves its slot: clear lane-w and lane-sl state
+            const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, l >> 6), l & 63);
+#pragma unroll
+            for (int q = 0; q < KW; ++q)
+              if (lane + 64 * q == l) {
+                wcid[q] = -1;
+                lam[q] = 0.0;
+                rw[q] = 0.0;
+              }
+            if (lane == de / 5) amask &= ~(1u << (de % 5));
+            if (lane == 0) S.state = ST_INNER_FAST;  // "continue"; the mode is set at the top of the pass
           }
         }
       }
       __syncthreads();
-      if (S.state != ST_INNER) break;
+      const int stt = S.state;
+      if (stt == ST_DONE || stt == ST_NEXT) break;
     }
   }
+  QMPC_TICK(6);
 
-  QMPC_TICK(8);
   // ------------------------------------------------------------ outputs
   // get_solution(0..11): forces of the four feet at horizon step 0
   // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685).
-  if (tid < 12) {
-    const int foot = tid / 3, ax = tid - 3 * foot;
-    float f = 0.f;
-    for (int sl = 0; sl < nst && sl < 4; ++sl)
-      if (S.sidx[sl] == foot) f = (float)S.x[3 * sl + ax];
-    P.grf[(size_t)rid * 12 + tid] = f;
-  }
-  if (P.soln) {
-    double* so = P.soln + (size_t)rid * 12 * h;
-    for (int k = tid; k < 12 * h; k += NT) so[k] = 0.0;
-    __syncthreads();
-    if (tid < n) so[3 * S.sidx[tid / 3] + (tid % 3)] = S.x[tid];
+  if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
+  __syncthreads();
+  if (engine && lane < nst) {
+    const int k = S.sidx[lane];
+    if (k < 4) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xs[ax];
+    }
+    if (P.soln) {
+      double* so = P.soln + (size_t)rid * 12 * h + 3 * k;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) so[ax] = xs[ax];
+    }
   }
   if (tid == 0) {
     P.status[rid] = S.status;
-    if (P.iters) P.iters[rid] = S.iters;
+    if (P.iters) P.iters[rid] = iters;
   }
   __syncthreads();
-  QMPC_TICK(9);
+  QMPC_TICK(7);
 }
 
 }  // namespace
 
-// One workgroup per robot (list == nullptr: robot = blockIdx.x, grid covers the
-// batch) or a persistent stride over a deferred-robot list (larger classes).
+// Class 1 (RB == 1): one workgroup per robot, robot = blockIdx.x.
+// Classes 2, 3: a persistent stride over the list of robots the previous class
+// deferred (usually empty).
 template <int RB>
 __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void qmpc_solve_kernel(const QmpcParams P) {
-  __shared__ Smem<RB> S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
+  Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   if (threadIdx.x == 0) S.par = P;
   __syncthreads();
-  const int cnt = S.par.list ? *S.par.count : S.par.batch;
+  if constexpr (RB == 1) {
+    solve_one<RB>((int)blockIdx.x, S);
+  } else {
+    const int cnt = *S.par.count;
 #pragma unroll 1
-  for (int it = blockIdx.x; it < cnt; it += gridDim.x) {
-    const int rid = S.par.list ? S.par.list[it] : it;
-    solve_one<RB>(S.par, rid, S);
+    for (int it = blockIdx.x; it < cnt; it += gridDim.x) solve_one<RB>(S.par.list[it], S);
+    // the last workgroup re-arms the list counter, so no memset has to precede
+    // the next solve call
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const int done = atomicAdd(S.par.done, 1);
+      if (done == (int)gridDim.x - 1) {
+        *S.par.count = 0;
+        *S.par.done = 0;
+        __threadfence();
+      }
+    }
   }
+}
+
+extern "C" size_t qmpc_smem_bytes(int rb) {
+  switch (rb) {
+    case 1: return sizeof(Smem<1>);
+    case 2: return sizeof(Smem<2>);
+    case 3: return sizeof(Smem<3>);
+  }
+  return 0;
+}
+
+extern "C" hipError_t qmpc_prepare(void) {
+  hipError_t e;
+  e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<1>));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<2>));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<3>));
+  return e;
 }
 
 extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
   switch (rb) {
-    case 1: hipLaunchKernelGGL(qmpc_solve_kernel<1>, dim3(grid), dim3(256), 0, stream, *P); break;
-    case 2: hipLaunchKernelGGL(qmpc_solve_kernel<2>, dim3(grid), dim3(512), 0, stream, *P); break;
-    case 3: hipLaunchKernelGGL(qmpc_solve_kernel<3>, dim3(grid), dim3(768), 0, stream, *P); break;
+    case 1: hipLaunchKernelGGL(qmpc_solve_kernel<1>, dim3(grid), dim3(256), sizeof(Smem<1>), stream, *P); break;
+    case 2: hipLaunchKernelGGL(qmpc_solve_kernel<2>, dim3(grid), dim3(512), sizeof(Smem<2>), stream, *P); break;
+    case 3: hipLaunchKernelGGL(qmpc_solve_kernel<3>, dim3(grid), dim3(768), sizeof(Smem<3>), stream, *P); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -16,14 +16,14 @@ clk = mpc.debug_clock(B)
 mpc.solve_async(B, inp, out); torch.cuda.synchronize()
 c = clk.cpu().numpy().astype(np.float64)
 it = o["iters"].cpu().numpy()
-names = ["0a gait", "0b scalars", "0c B/e", "0d E/s", "1 asm H", "2 sweep", "3 x_u", "4 active set", "out"]
-d = np.diff(c[:, :10], axis=1)
+names = ["0 inputs", "1 E/s", "2 asm H,g", "3 sweep", "4 x_u", "5 active set", "6 out"]
+d = np.diff(c[:, :8], axis=1)
 print(f"cfg{cfg} B={B}: per-phase shader cycles (median / mean / max over blocks); iters mean {it.mean():.2f}")
 for k, nm in enumerate(names):
     print(f"  {nm:14s} {np.median(d[:,k]):9.0f} {d[:,k].mean():9.0f} {d[:,k].max():9.0f}")
-tot = c[:, 9] - c[:, 0]
+tot = c[:, 7] - c[:, 0]
 print(f"  total          {np.median(tot):9.0f} {tot.mean():9.0f} {tot.max():9.0f}")
-print(f"  kernel span (max end - min start) {c[:,9].max()-c[:,0].min():.0f} cycles; start spread {c[:,0].max()-c[:,0].min():.0f}")
+print(f"  kernel span (max end - min start) {c[:,7].max()-c[:,0].min():.0f} cycles; start spread {c[:,0].max()-c[:,0].min():.0f}")
 sel = it > 0
 if sel.any():
-    print(f"  active-set cycles per iteration (blocks with it>0): {np.median(d[sel,7]/it[sel]):.0f}")
+    print(f"  active-set cycles per iteration (blocks with it>0): {np.median(d[sel,5]/it[sel]):.0f}")
