@@ -160,7 +160,7 @@ struct Smem {
   using C = Cfg<RB>;
   // ---- live for the whole solve
   QmpcParams par;  // kernel parameters parked in LDS (keeps ~45 uniforms out of SGPRs)
-  alignas(16) double colbuf[2][C::NP + 2];
+  alignas(16) double colbuf[2][2][C::NP + 2];  // [parity][column of the pair][row]
   double g[C::NP];
   double fmaxk[64];
   unsigned char sidx[64];
@@ -192,6 +192,11 @@ struct Smem {
 enum { ST_NEXT = 0, ST_INNER_FAST = 1, ST_INNER_MATVEC = 2, ST_DONE = 3 };
 
 // phase timestamps (profiling hook; dbg_clk == nullptr in production)
+// fine-grained stamps inside the FIRST active-set iteration
+#define QMPC_TICK1(k)                                                \
+  do {                                                               \
+    if (dbg_clk && tid == 0 && iters == 0) dbg_clk[(k)] = clock64(); \
+  } while (0)
 #define QMPC_TICK(k)                                   \
   do {                                                 \
     if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); \
@@ -448,53 +453,78 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   QMPC_TICK(3);
 
   // ------------------------------------------------------------ stage 3
-  // n symmetric Gauss-Jordan sweeps: a <- -H^-1, one barrier per pivot.
-  // Pivot column k lives in column group k / CW, register k % CW, and is
-  // broadcast through a double-buffered LDS vector (row k == column k by
-  // symmetry).  Pivot row trick: a_kj <- a_kj/d  ==  a_kj - ((d-1)/d) c_j, so the
-  // rank-1 update is one fma per element with no row special-casing.
+  // Symmetric Gauss-Jordan sweeps, TWO pivots per barrier: a <- -H^-1.
+  // Pivot columns k0 = 2m, k1 = k0+1 live in column group k0 / CW, registers
+  // k0 % CW and +1, and are broadcast through a double-buffered pair of LDS
+  // vectors (row k == column k by symmetry).  Every thread applies pivot k0 to
+  // its copy of column k1 locally (c1' = c1 - c0 e/d0), so the second pivot
+  // needs no second broadcast:
+  //     a_ij <- a_ij - f0_i c0_j - f1_i c1'_j ,  f0 = c0/d0 , f1 = c1'/d1
+  //          = a_ij - (f0_i - f1_i g) c0_j - f1_i c1_j ,  g = e/d0 .
+  // Pivot-row trick: a_kj <- a_kj/d == a_kj - ((d-1)/d) c_j, i.e. the pivot
+  // rows use f = (d-1)/d and need no special casing in the update.
   bool notpd = false;
   {
-    // software pipeline: the owner updates and publishes column k+1 BEFORE the
-    // rank-1 update for pivot k, so the LDS write latency and most of the
-    // barrier wait overlap that update; the column is then re-read after the
-    // barrier into the same registers.
-    if (c == 0) S.colbuf[0][i] = a[0];
+    if (c == 0) {
+      S.colbuf[0][0][i] = a[0];
+      S.colbuf[0][1][i] = a[1];
+    }
     __syncthreads();
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
-      StaticFor<0, CW>::run([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        constexpr int rn = (r + 1 < CW) ? r + 1 : 0;
-        const int k = kb * CW + r;
-        if (k < n) {
-          const double* cb = S.colbuf[k & 1];
-          double d = cb[k];
-          const double ci = cb[i];
-          double cj[CW];
-#pragma unroll
-          for (int jj = 0; jj < CW; ++jj) cj[jj] = cb[c * CW + jj];
-          if (!(d > 1e-300)) {
+      StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
+        constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
+        constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
+        const int k0 = kb * CW + r0, k1 = k0 + 1;  // k1 == n: identity padding column, a no-op pivot
+        if (k0 < n) {
+          const int m = k0 >> 1;
+          if (dbg_clk && tid == 0 && (k0 == 10 || k0 == 12)) dbg_clk[k0 == 10 ? 8 : 11] = clock64();
+          const double* cb0 = S.colbuf[m & 1][0];
+          const double* cb1 = S.colbuf[m & 1][1];
+          double d0 = cb0[k0];
+          const double e = cb0[k1];  // A[k1][k0]
+          const double d1p = cb1[k1];
+          const double c0i = cb0[i], c1i = cb1[i];
+          if (!(d0 > 1e-300)) {
             notpd = true;
-            d = 1e-300;
+            d0 = 1e-300;
           }
-          const double dinv = fast_rcp(d);
-          const bool prow = (i == k);
-          const double f = (prow ? (d - 1.0) : ci) * dinv;
-          // -- next pivot column first
-          const int kbn = (r + 1 < CW) ? kb : kb + 1;
-          const bool own_next = (k + 1 < n) && (c == kbn);
-          if (own_next) {
-            a[rn] = __builtin_fma(-f, cj[rn], a[rn]);
-            S.colbuf[(k + 1) & 1][i] = a[rn];
+          const double dinv0 = fast_rcp(d0);
+          const double g = e * dinv0;
+          double d1 = __builtin_fma(-e, g, d1p);  // pivot k1 after pivot k0
+          if (!(d1 > 1e-300)) {
+            notpd = true;
+            d1 = 1e-300;
           }
-          // -- rank-1 update for pivot k
+          const double dinv1 = fast_rcp(d1);
+          const bool p0 = (i == k0), p1 = (i == k1);
+          const double f0 = (p0 ? d0 - 1.0 : c0i) * dinv0;
+          const double c1pi = __builtin_fma(-f0, e, c1i);
+          const double f1 = (p1 ? d1 - 1.0 : c1pi) * dinv1;
+          // f0 c0_j + f1 c1'_j == (f0 - f1 g) c0_j + f1 c1_j : no per-element c1'
+          const double f0g = __builtin_fma(-f1, g, f0);
+          if (dbg_clk && tid == 0 && k0 == 10) {
+            dbg_clk[9] = clock64();
+            asm volatile("" ::"v"(f0g), "v"(f1));
+          }
 #pragma unroll
-          for (int jj = 0; jj < CW; ++jj) {
-            const double upd = __builtin_fma(-f, cj[jj], a[jj]);
-            a[jj] = (jj == rn && own_next) ? a[jj] : upd;
+          for (int jj = 0; jj < CW; ++jj)
+            a[jj] = __builtin_fma(-f1, cb1[c * CW + jj], __builtin_fma(-f0g, cb0[c * CW + jj], a[jj]));
+          if (dbg_clk && tid == 0 && k0 == 10) {
+            asm volatile("" ::"v"(a[0]), "v"(a[CW - 1]), "v"(a[CW / 2]));
+            dbg_clk[10] = clock64();
           }
-          if (c == kb) a[r] = prow ? -dinv : f;  // column k itself
+          if (c == kb) {
+            // column k0: f0 (pivot entry -1/d0) after pivot k0, then pivot k1 with
+            // A'[k1][k0] = g ; column k1: f1 (pivot entry -1/d1)
+            a[r0] = __builtin_fma(-f1, g, p0 ? -dinv0 : f0);
+            a[r1] = p1 ? -dinv1 : f1;
+          }
+          const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
+          if (k0 + 2 < n && c == kbn) {
+            S.colbuf[(m + 1) & 1][0][i] = a[rn0];
+            S.colbuf[(m + 1) & 1][1][i] = a[rn1];
+          }
           __syncthreads();
         }
       });
@@ -625,6 +655,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       if (a2 != 0.0) put_col(j2, Sb.rowB);
     }
     __syncthreads();
+    QMPC_TICK1(8);
     // hc = H^-1 c_p, slot-major in the engine: lane sl holds hc[3sl..3sl+2]
     double hcs[3] = {0.0, 0.0, 0.0};
     double hcn = 0.0;  // c_p^T H^-1 c_p
@@ -654,29 +685,48 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           }
           rw[q] = 0.0;
         }
-        for (int v = 0; v < khw; ++v) {
-          const double dv = readlane_f64(pick<KW>(dw, v >> 6), v & 63);
-          if (dv != 0.0) {
+        QMPC_TICK1(9);
+        for (int v0 = 0; v0 < khw; v0 += 4) {
+          // 4 entries of row w of S_W^-1 per lane, loaded back-to-back (one LDS latency)
+          double sv[KW][4];
 #pragma unroll
-            for (int q = 0; q < KW; ++q) {
-              const int w = lane + 64 * q;
-              if (w < khw) rw[q] = __builtin_fma(Sb.Sinv[sym_idx(w, v)], dv, rw[q]);
+          for (int q = 0; q < KW; ++q) {
+            const int w = lane + 64 * q;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int v = v0 + u;
+              sv[q][u] = (w < khw && v < khw) ? Sb.Sinv[sym_idx(w, v)] : 0.0;
             }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int v = v0 + u;  // slots >= khw hold d = 0
+            const double dv = readlane_f64(pick<KW>(dw, (v >> 6) < KW ? (v >> 6) : 0), v & 63);
+#pragma unroll
+            for (int q = 0; q < KW; ++q) rw[q] = __builtin_fma(sv[q][u], dv, rw[q]);
           }
         }
 #pragma unroll
         for (int q = 0; q < KW; ++q)
           if (wcid[q] < 0) rw[q] = 0.0;
+        QMPC_TICK1(10);
         const int mode = (khw <= MCAP) ? ST_INNER_FAST : ST_INNER_MATVEC;
         if (mode == ST_INNER_FAST) {
           // z = hc - M r  with the rows M[w] = H^-1 c_w kept in LDS
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) zs[ax] = hcs[ax];
-          for (int w = 0; w < khw; ++w) {
-            const double rv = readlane_f64(rw[0], w);  // MCAP <= 64: slot w lives in q = 0
-            if (rv != 0.0 && lane < nst) {
+          for (int w0 = 0; w0 < khw; w0 += 4) {
+            double mv[4][3];
 #pragma unroll
-              for (int ax = 0; ax < 3; ++ax) zs[ax] = __builtin_fma(-rv, Sb.M[w][3 * lane + ax], zs[ax]);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int ax = 0; ax < 3; ++ax)
+                mv[u][ax] = (w0 + u < khw && lane < nst) ? Sb.M[w0 + u][3 * lane + ax] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double rv = readlane_f64(rw[0], (w0 + u) & 63);  // MCAP <= 64: slot lives in q = 0
+#pragma unroll
+              for (int ax = 0; ax < 3; ++ax) zs[ax] = __builtin_fma(-rv, mv[u][ax], zs[ax]);
             }
           }
         } else {
@@ -731,6 +781,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         }
       }
       if (engine) {
+        QMPC_TICK1(11);
         // delta = c_p^T z, current violation of p, step lengths
         const int psl = p_e / 5, pty = p_e - 5 * psl;
         const int ax1 = pj1 - 3 * psl;  // axis of the first coefficient (2 for the f_max row)
@@ -739,14 +790,15 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         const double delta = readlane_f64(dloc, psl);
         const double sp = readlane_f64(sloc, psl);
         const bool dep = !(delta > 1e-12 * hcn);
-        const double t2 = dep ? __builtin_inf() : -sp / delta;
+        const double rdelta = fast_rcp(dep ? 1.0 : delta);
+        const double t2 = dep ? __builtin_inf() : -sp * rdelta;
         // t1: largest dual step keeping the working-set multipliers >= 0
         double ratio = __builtin_inf();
         int lq = 0;
 #pragma unroll
         for (int q = 0; q < KW; ++q) {
           if (wcid[q] >= 0 && rw[q] > 0.0) {
-            double qv = lam[q] / rw[q];
+            double qv = lam[q] * fast_rcp(rw[q]);
             qv = qv > 0.0 ? qv : 0.0;
             if (qv < ratio) {
               ratio = qv;
@@ -762,6 +814,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           l = ll + 64 * __builtin_amdgcn_readlane(lq, ll);
         }
         const double t = (t2 <= t1) ? t2 : t1;
+        QMPC_TICK1(12);
         if (!(t < __builtin_inf())) {
           if (lane == 0) {
             S.status |= QMPC_DEV_ST_INFEASIBLE;
@@ -792,22 +845,33 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
               }
             } else {
               const int kn = (qslot + 1 > khw) ? qslot + 1 : khw;
-              const double dinv = 1.0 / delta;
+              const double dinv = rdelta;
               // bordered-inverse update of S_W^-1 (free slots have r = 0):
               //   S[a][b] += r_a r_b / delta ; S[q][a] = -r_a / delta ; S[q][q] = 1/delta
-              for (int hi = 0; hi < kn; ++hi) {
-                const double rhi = readlane_f64(pick<KW>(rw, hi >> 6), hi & 63);
+              for (int h0 = 0; h0 < kn; h0 += 4) {
+                double old[KW][4];
 #pragma unroll
-                for (int q = 0; q < KW; ++q) {
-                  const int lo = lane + 64 * q;
-                  if (lo <= hi) {
-                    const int idx = hi * (hi + 1) / 2 + lo;
-                    double v;
-                    if (hi == qslot && lo == qslot) v = dinv;
-                    else if (hi == qslot) v = -rw[q] * dinv;
-                    else if (lo == qslot) v = -rhi * dinv;
-                    else v = __builtin_fma(rhi * dinv, rw[q], Sb.Sinv[idx]);
-                    Sb.Sinv[idx] = v;
+                for (int q = 0; q < KW; ++q)
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const int hi = h0 + u, lo = lane + 64 * q;
+                    old[q][u] = (hi < kn && lo <= hi) ? Sb.Sinv[hi * (hi + 1) / 2 + lo] : 0.0;
+                  }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int hi = h0 + u;
+                  const double rhi = readlane_f64(pick<KW>(rw, (hi >> 6) < KW ? (hi >> 6) : 0), hi & 63);
+#pragma unroll
+                  for (int q = 0; q < KW; ++q) {
+                    const int lo = lane + 64 * q;
+                    if (hi < kn && lo <= hi) {
+                      double v;
+                      if (hi == qslot && lo == qslot) v = dinv;
+                      else if (hi == qslot) v = -rw[q] * dinv;
+                      else if (lo == qslot) v = -rhi * dinv;
+                      else v = __builtin_fma(rhi * dinv, rw[q], old[q][u]);
+                      Sb.Sinv[hi * (hi + 1) / 2 + lo] = v;
+                    }
                   }
                 }
               }
@@ -829,13 +893,15 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
                   if (ty == pty) aslot[ty] = (unsigned)qslot;
               }
               khw = kn;
+              if (dbg_clk && tid == 0 && iters == 1) dbg_clk[13] = clock64();
               select();  // next violated constraint, or DONE
+              if (dbg_clk && tid == 0 && iters == 1) dbg_clk[14] = clock64();
             }
           } else {
             // partial step: the multiplier of slot l hit zero -> drop it.
             //   S' = S - S[:,l] S[l,:] / S[l,l] on the other slots; row/col l is
             //   only read here and zeroed afterwards, so in place is safe.
-            const double il = 1.0 / Sb.Sinv[sym_idx(l, l)];
+            const double il = fast_rcp(Sb.Sinv[sym_idx(l, l)]);
             for (int hi = 0; hi < khw; ++hi) {
               if (hi == l) continue;
               const double shl = Sb.Sinv[sym_idx(hi, l)] * il;
@@ -869,6 +935,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         }
       }
       __syncthreads();
+      if (dbg_clk && tid == 0 && iters == 1) dbg_clk[15] = clock64();
       const int stt = S.state;
       if (stt == ST_DONE || stt == ST_NEXT) break;
     }
