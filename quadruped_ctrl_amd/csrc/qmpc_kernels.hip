@@ -149,10 +149,12 @@ struct Cfg {
   static constexpr int NP = 64 * RB;
   static constexpr int CW = 16 * RB;
   static constexpr int NT = 256 * RB;
-  static constexpr int KMAX = (RB == 1) ? 64 : (RB == 2 ? 96 : 128);  // working-set slots
-  static constexpr int KW = (KMAX + 63) / 64;                         // slots per engine lane
-  static constexpr int MCAP = (RB == 1) ? 24 : (RB == 2 ? 16 : 8);    // rows of H^-1 C_W kept in LDS
+  // working-set slots: every n_r <= 64 problem fits 64; the largest class is
+  // bounded by the 160 KiB of LDS next to its 148 KiB inverse
+  static constexpr int KMAX = (RB == 1) ? 64 : (RB == 2 ? 96 : 48);
+  static constexpr int KW = (KMAX + 63) / 64;  // slots per engine lane
   static constexpr int NS = KMAX * (KMAX + 1) / 2;
+  static constexpr int NH = NP * (NP + 1) / 2;
 };
 
 template <int RB>
@@ -160,36 +162,35 @@ struct Smem {
   using C = Cfg<RB>;
   // ---- live for the whole solve
   QmpcParams par;  // kernel parameters parked in LDS (keeps ~45 uniforms out of SGPRs)
-  alignas(16) double colbuf[2][2][C::NP + 2];  // [parity][column of the pair][row]
-  double g[C::NP];
   double fmaxk[64];
   unsigned char sidx[64];
-  int nst, state, status, p_e;
+  int nst, status;
   // ---- phase-local storage
   union U {
-    struct Asm {  // linearisation + assembly
-      double Mb[4][9];  // M_b = I_world^-1 [r_b]x                 (B0 rows 6..8)
-      double Nb[4][9];  // N_b = R_yaw^T M_b                       (B1 rows 0..2)
-      double W[12];
-      double coef[3 * 16];
-      double ct0[256], ct4[256];            // C_00 (tau), C_11 (sigma)
-      double ct1[256], ct5[256], ct8[256];  // C_01, C_12, C_22 (x_drag != 0 only)
-      double E00[144], E11[144];
-      double e[16 * 12];
-      double s[3][16 * 12];
-    } a;
-    struct Slv {  // active-set solve
-      double Sinv[C::NS];
-      double M[C::MCAP][C::NP];
-      alignas(16) double y[C::NP];
-      double part[4][C::NP];
-      double rowA[C::NP], rowB[C::NP];
+    struct AW {
+      struct Asm {  // linearisation + assembly (stages 0-2)
+        double Mb[4][9];  // M_b = I_world^-1 [r_b]x                 (B0 rows 6..8)
+        double Nb[4][9];  // N_b = R_yaw^T M_b                       (B1 rows 0..2)
+        double W[12];
+        double coef[3 * 16];
+        double ct0[256], ct4[256];            // C_00 (tau), C_11 (sigma)
+        double ct1[256], ct5[256], ct8[256];  // C_01, C_12, C_22 (x_drag != 0 only)
+        double E00[144], E11[144];
+        double e[16 * 12];
+        double s[3][16 * 12];
+      } a;
+      struct Swp {  // sweep + unconstrained minimiser (stages 2-4)
+        alignas(16) double colbuf[2][2][C::NP + 2];  // [parity][column of the pair][row]
+        double g[C::NP];
+        double part[4][C::NP];
+      } w;
+    } aw;
+    struct Slv {  // active-set solve (stage 5): the engine wave's working storage
+      double Hp[C::NH];    // H^-1, packed lower triangle: (i,j), i >= j, at i(i+1)/2 + j
+      double Sinv[C::NS];  // (C_W^T H^-1 C_W)^-1, packed the same way
     } b;
   } u;
 };
-
-// block-wide state word written by the engine wave
-enum { ST_NEXT = 0, ST_INNER_FAST = 1, ST_INNER_MATVEC = 2, ST_DONE = 3 };
 
 // phase timestamps (profiling hook; dbg_clk == nullptr in production)
 // fine-grained stamps inside the FIRST active-set iteration
@@ -205,7 +206,7 @@ enum { ST_NEXT = 0, ST_INNER_FAST = 1, ST_INNER_MATVEC = 2, ST_DONE = 3 };
 template <int RB>
 __device__ void solve_one(const int rid, Smem<RB>& S) {
   using C = Cfg<RB>;
-  constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, MCAP = C::MCAP;
+  constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW;
   const QmpcParams& P = S.par;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
@@ -237,7 +238,8 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   if (P.soln)  // q_soln is zero on swing feet (SolverMPC.cpp:545-551)
     for (int k = tid; k < 12 * h; k += NT) P.soln[(size_t)rid * 12 * h + k] = 0.0;
 
-  auto& Aa = S.u.a;
+  auto& Aa = S.u.aw.a;
+  auto& Sw = S.u.aw.w;
   const double x_drag = (double)P.x_drag[(size_t)rid * P.x_drag_stride];
   const bool drag = (x_drag != 0.0);
   const double inv_m = 1.0 / P.mass;
@@ -400,7 +402,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       if (drag && ax == 0) acc += (x_drag * inv_m) * (s1[11] + Aa.s[2][st * 12 + 5]);
       gv = 2.0 * acc;
     }
-    S.g[tid] = gv;
+    Sw.g[tid] = gv;
   }
 
   double a[CW];
@@ -441,14 +443,14 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         cax = 0;
         ++cslot;
       }
-      if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+      if ((jj & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
     }
   }
   if (P.dbg_H) {
     double* Hd = P.dbg_H + (size_t)rid * QMPC_DBG_LD * QMPC_DBG_LD;
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) Hd[(size_t)i * QMPC_DBG_LD + c * CW + jj] = a[jj];
-    if (tid < NP) P.dbg_g[(size_t)rid * QMPC_DBG_LD + tid] = S.g[tid];
+    if (tid < NP) P.dbg_g[(size_t)rid * QMPC_DBG_LD + tid] = Sw.g[tid];
   }
   QMPC_TICK(3);
 
@@ -466,8 +468,8 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   bool notpd = false;
   {
     if (c == 0) {
-      S.colbuf[0][0][i] = a[0];
-      S.colbuf[0][1][i] = a[1];
+      Sw.colbuf[0][0][i] = a[0];
+      Sw.colbuf[0][1][i] = a[1];
     }
     __syncthreads();
 #pragma unroll 1
@@ -478,9 +480,8 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         const int k0 = kb * CW + r0, k1 = k0 + 1;  // k1 == n: identity padding column, a no-op pivot
         if (k0 < n) {
           const int m = k0 >> 1;
-          if (dbg_clk && tid == 0 && (k0 == 10 || k0 == 12)) dbg_clk[k0 == 10 ? 8 : 11] = clock64();
-          const double* cb0 = S.colbuf[m & 1][0];
-          const double* cb1 = S.colbuf[m & 1][1];
+          const double* cb0 = Sw.colbuf[m & 1][0];
+          const double* cb1 = Sw.colbuf[m & 1][1];
           double d0 = cb0[k0];
           const double e = cb0[k1];  // A[k1][k0]
           const double d1p = cb1[k1];
@@ -503,17 +504,9 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           const double f1 = (p1 ? d1 - 1.0 : c1pi) * dinv1;
           // f0 c0_j + f1 c1'_j == (f0 - f1 g) c0_j + f1 c1_j : no per-element c1'
           const double f0g = __builtin_fma(-f1, g, f0);
-          if (dbg_clk && tid == 0 && k0 == 10) {
-            dbg_clk[9] = clock64();
-            asm volatile("" ::"v"(f0g), "v"(f1));
-          }
 #pragma unroll
           for (int jj = 0; jj < CW; ++jj)
             a[jj] = __builtin_fma(-f1, cb1[c * CW + jj], __builtin_fma(-f0g, cb0[c * CW + jj], a[jj]));
-          if (dbg_clk && tid == 0 && k0 == 10) {
-            asm volatile("" ::"v"(a[0]), "v"(a[CW - 1]), "v"(a[CW / 2]));
-            dbg_clk[10] = clock64();
-          }
           if (c == kb) {
             // column k0: f0 (pivot entry -1/d0) after pivot k0, then pivot k1 with
             // A'[k1][k0] = g ; column k1: f1 (pivot entry -1/d1)
@@ -522,157 +515,136 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           }
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
-            S.colbuf[(m + 1) & 1][0][i] = a[rn0];
-            S.colbuf[(m + 1) & 1][1][i] = a[rn1];
+            Sw.colbuf[(m + 1) & 1][0][i] = a[rn0];
+            Sw.colbuf[(m + 1) & 1][1][i] = a[rn1];
           }
           __syncthreads();
         }
       });
     }
   }
-  if (notpd && tid == 0) S.status |= QMPC_DEV_ST_NOT_PD;
+  if (notpd) S.status = QMPC_DEV_ST_NOT_PD;  // benign race: same value from every thread
   QMPC_TICK(4);
 
   auto& Sb = S.u.b;
   // ------------------------------------------------------------ stage 4
-  // unconstrained minimiser x = -H^-1 g = a * g   (distributed mat-vec)
+  // unconstrained minimiser x = -H^-1 g = a * g   (distributed mat-vec), then
+  // the inverse leaves the registers: packed lower triangle in LDS.
   {
     double acc = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < CW; ++jj) acc = __builtin_fma(a[jj], S.g[c * CW + jj], acc);
-    __syncthreads();  // assembly storage (union) is dead from here on
-    Sb.part[c][i] = acc;
-    for (int k = tid; k < C::NS; k += NT) Sb.Sinv[k] = 0.0;
+    for (int jj = 0; jj < CW; ++jj) acc = __builtin_fma(a[jj], Sw.g[c * CW + jj], acc);
+    Sw.part[c][i] = acc;
   }
   __syncthreads();
-  QMPC_TICK(5);
-
-  // ------------------------------------------------------------ stage 5
-  // Goldfarb-Idnani dual active set on the explicit inverse.  Wave 0 is the
-  // engine and keeps its state in registers:
-  //   lane = stance slot sl : x[3sl..3sl+2], working-set membership of its 5 rows
-  //   lane = working-set slot w (+64q): constraint id, multiplier, r_w
-  // The other waves only serve columns of the register-resident -H^-1 (one
-  // ds_write per lane) and, past MCAP working constraints, mat-vecs.
   const bool engine = tid < WAVE;
-  const double mi = P.mu_inv;
-  const double inv_fr = P.inv_fr_norm;
-  const double tol = P.tol;
-  const int max_iter = P.max_iter;
-
   double xs[3] = {0.0, 0.0, 0.0};  // engine lane sl: forces of stance slot sl
   double fmx = 0.0;                // its f_max
-  unsigned amask = 0;              // bit ty: constraint (sl, ty) is in the working set
-  unsigned aslot[5] = {0, 0, 0, 0, 0};  // ... and the working-set slot holding it
-  int wcid[KW];                    // engine lane w: constraint id in slot w + 64 q, -1 = free
-  double lam[KW], rw[KW];
-  int khw = 0;                     // high-water mark of used working-set slots (uniform)
-  int iters = 0;
-  double lp = 0.0;                 // multiplier of the constraint being added
-  // uniform description of the constraint being added
-  int p_e = -1, pj1 = 0, pj2 = 0;
-  double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0;
-#pragma unroll
-  for (int q = 0; q < KW; ++q) {
-    wcid[q] = -1;
-    lam[q] = 0.0;
-    rw[q] = 0.0;
-  }
   if (engine && lane < nst) {
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
       const int j = 3 * lane + ax;
-      xs[ax] = Sb.part[0][j] + Sb.part[1][j] + Sb.part[2][j] + Sb.part[3][j];
+      xs[ax] = Sw.part[0][j] + Sw.part[1][j] + Sw.part[2][j] + Sw.part[3][j];
     }
     fmx = S.fmaxk[lane];
   }
-
-  // engine: pick the most violated inactive constraint (normalised by the row
-  // norm); publish it (state NEXT) or finish (state DONE)
-  auto select = [&]() __attribute__((always_inline)) {
-    unsigned key = 0;
-    if (lane < nst) {
-      const double sv[5] = {(mi * xs[0] + xs[2]) * inv_fr, (-mi * xs[0] + xs[2]) * inv_fr,
-                            (mi * xs[1] + xs[2]) * inv_fr, (-mi * xs[1] + xs[2]) * inv_fr, fmx - xs[2]};
+  __syncthreads();  // sweep storage (and the assembly storage under it) is dead: Slv may overwrite it
+  if (i < n) {
+    // opaque copies of the indices: keeps the compiler from carrying values that
+    // it pre-computed during assembly across the whole sweep (they were spilled)
+    int io = i, co = c * CW;
+    asm volatile("" : "+v"(io), "+v"(co));
+    const int rb = io * (io + 1) / 2;
 #pragma unroll
-      for (int ty = 0; ty < 5; ++ty) {
-        if (!((amask >> ty) & 1u) && sv[ty] < -tol) {
-          // more negative -> larger float magnitude -> larger key; low 9 bits = id
-          const unsigned kk = (__float_as_uint((float)(-sv[ty])) & ~0x1FFu) | (unsigned)(5 * lane + ty);
-          key = kk > key ? kk : key;
-        }
-      }
+    for (int jj = 0; jj < CW; ++jj) {
+      const int j = co + jj;
+      if (j <= io) Sb.Hp[rb + j] = -a[jj];
+      if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
-    const unsigned best = wave_max_u32(key);
-    if (best == 0u) {
-      if (lane == 0) S.state = ST_DONE;
-      p_e = -1;
-    } else if (iters >= max_iter) {
-      if (lane == 0) {
-        S.status |= QMPC_DEV_ST_MAXITER;
-        S.state = ST_DONE;
-      }
-      p_e = -1;
-    } else {
-      p_e = (int)(best & 0x1FFu);
-      con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
-      const double fm_p = readlane_f64(fmx, p_e / 5);
-      p_rhs = (p_e % 5 == 4) ? -fm_p : 0.0;
-      lp = 0.0;
-      if (lane == 0) {
-        S.p_e = p_e;
-        S.state = ST_NEXT;
-      }
-    }
-  };
-
-  if (engine) select();
+  }
+  for (int k = tid; k < C::NS; k += NT) Sb.Sinv[k] = 0.0;
   __syncthreads();
+  QMPC_TICK(5);
 
-  while (S.state != ST_DONE) {
-    // --- columns j1, j2 of H^-1 (= -a; row == column by symmetry) out of the
-    //     registers: the owning column group stores one value per lane.
-    {
-      int j1, j2;
-      double a1, a2;
-      con_coefs(S.p_e, mi, j1, j2, a1, a2);
-      auto put_col = [&](int j, double* dst) __attribute__((always_inline)) {
-        if (c == j / CW) {
-          const int r = j % CW;  // uniform
-          // select by VALUE: the empty asm keeps LLVM from turning the chain into a
-          // select of addresses + one dynamic load, which would force a[] to scratch
-          double v = a[0];
+  // ------------------------------------------------------------ stage 5
+  // Goldfarb-Idnani dual active set on the explicit inverse, run by wave 0
+  // alone: no block barrier inside the loop.  Engine state lives in registers:
+  //   lane = stance slot sl : x[3sl..3sl+2], working-set membership of its 5 rows
+  //   lane = working-set slot w (+64q): constraint id, multiplier, r_w
+  // and all matrix data comes from the packed H^-1 and S_W^-1 in LDS.
+  int iters = 0;
+  if (engine) {
+    const double mi = P.mu_inv;
+    const double inv_fr = P.inv_fr_norm;
+    const double tol = P.tol;
+    const int max_iter = P.max_iter;
+    auto Hinv = [&](int r, int cidx) __attribute__((always_inline)) {
+      const int hi = r > cidx ? r : cidx, lo = r > cidx ? cidx : r;
+      return Sb.Hp[hi * (hi + 1) / 2 + lo];
+    };
+
+    unsigned amask = 0;  // bit ty: constraint (sl, ty) is in the working set
+    int wcid[KW];        // engine lane w: constraint id in slot w + 64 q, -1 = free
+    double lam[KW], rw[KW];
+    int khw = 0;         // high-water mark of used working-set slots (uniform)
+    int status = 0;
 #pragma unroll
-          for (int q = 1; q < CW; ++q) {
-            double t = a[q];
-            asm volatile("" : "+v"(t));
-            v = (r == q) ? t : v;
-          }
-          dst[i] = -v;
-        }
-      };
-      put_col(j1, Sb.rowA);
-      if (a2 != 0.0) put_col(j2, Sb.rowB);
+    for (int q = 0; q < KW; ++q) {
+      wcid[q] = -1;
+      lam[q] = 0.0;
+      rw[q] = 0.0;
     }
-    __syncthreads();
-    QMPC_TICK1(8);
-    // hc = H^-1 c_p, slot-major in the engine: lane sl holds hc[3sl..3sl+2]
-    double hcs[3] = {0.0, 0.0, 0.0};
-    double hcn = 0.0;  // c_p^T H^-1 c_p
-    const bool two = (pa2 != 0.0);
-    auto hc_at = [&](int j) __attribute__((always_inline)) { return pa1 * Sb.rowA[j] + (two ? pa2 * Sb.rowB[j] : 0.0); };
-    if (engine) {
+
+    while (true) {
+      // ---- pick the most violated constraint outside the working set
+      //      (normalised by its row norm); none -> optimal
+      unsigned key = 0;
+      if (lane < nst) {
+        const double sv[5] = {(mi * xs[0] + xs[2]) * inv_fr, (-mi * xs[0] + xs[2]) * inv_fr,
+                              (mi * xs[1] + xs[2]) * inv_fr, (-mi * xs[1] + xs[2]) * inv_fr, fmx - xs[2]};
+#pragma unroll
+        for (int ty = 0; ty < 5; ++ty) {
+          if (!((amask >> ty) & 1u) && sv[ty] < -tol) {
+            // more negative -> larger float magnitude -> larger key; low 9 bits = id
+            const unsigned kk = (__float_as_uint((float)(-sv[ty])) & ~0x1FFu) | (unsigned)(5 * lane + ty);
+            key = kk > key ? kk : key;
+          }
+        }
+      }
+      const unsigned best = wave_max_u32(key);
+      if (best == 0u) break;
+      if (iters >= max_iter) {
+        status |= QMPC_DEV_ST_MAXITER;
+        break;
+      }
+      // uniform description of the constraint p being added: c_p = pa1 e_pj1 + pa2 e_pj2
+      const int p_e = (int)(best & 0x1FFu);
+      const int psl = p_e / 5, pty = p_e - 5 * psl;
+      int pj1, pj2;
+      double pa1, pa2;
+      con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+      const bool two = (pa2 != 0.0);
+      const int ax1 = pj1 - 3 * psl;  // axis of the first coefficient (2 for the f_max row)
+      const double p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
+      if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
+
+      // hc = H^-1 c_p, slot-major: lane sl holds hc[3sl..3sl+2]
+      double hcs[3] = {0.0, 0.0, 0.0};
       if (lane < nst) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) hcs[ax] = hc_at(3 * lane + ax);
+        for (int ax = 0; ax < 3; ++ax) {
+          const int row = 3 * lane + ax;
+          hcs[ax] = pa1 * Hinv(row, pj1) + (two ? pa2 * Hinv(row, pj2) : 0.0);
+        }
       }
-      hcn = pa1 * hc_at(pj1) + (two ? pa2 * hc_at(pj2) : 0.0);
-    }
-    // --- inner loop: one pass per (partial or full) step
-    while (true) {
-      double zs[3] = {0.0, 0.0, 0.0};
-      if (engine) {
-        // d = C_W^T H^-1 c_p (lane = working-set slot), r = S_W^-1 d
+      // c_p^T H^-1 c_p : both coefficients live in slot psl
+      const double hcn = readlane_f64(pa1 * (ax1 == 0 ? hcs[0] : (ax1 == 1 ? hcs[1] : hcs[2])) + pa2 * hcs[2], psl);
+      double lp = 0.0;  // multiplier of p
+      bool done = false;
+
+      // ---- inner loop: one pass per (partial or full) step
+      while (true) {
+        // d = C_W^T H^-1 c_p (lane = working-set slot): 4 gathers from the packed inverse
         double dw[KW];
 #pragma unroll
         for (int q = 0; q < KW; ++q) {
@@ -681,14 +653,15 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
             int j1, j2;
             double a1, a2;
             con_coefs(wcid[q], mi, j1, j2, a1, a2);
-            dw[q] = a1 * hc_at(j1) + (a2 != 0.0 ? a2 * hc_at(j2) : 0.0);
+            const double h1 = pa1 * Hinv(j1, pj1) + (two ? pa2 * Hinv(j1, pj2) : 0.0);
+            const double h2 = (a2 != 0.0) ? pa1 * Hinv(j2, pj1) + (two ? pa2 * Hinv(j2, pj2) : 0.0) : 0.0;
+            dw[q] = a1 * h1 + a2 * h2;
           }
           rw[q] = 0.0;
         }
-        QMPC_TICK1(9);
+        // r = S_W^-1 d
         for (int v0 = 0; v0 < khw; v0 += 4) {
-          // 4 entries of row w of S_W^-1 per lane, loaded back-to-back (one LDS latency)
-          double sv[KW][4];
+          double sv[KW][4];  // 4 entries of row w per lane, loaded back-to-back (one LDS latency)
 #pragma unroll
           for (int q = 0; q < KW; ++q) {
             const int w = lane + 64 * q;
@@ -709,82 +682,26 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
 #pragma unroll
         for (int q = 0; q < KW; ++q)
           if (wcid[q] < 0) rw[q] = 0.0;
-        QMPC_TICK1(10);
-        const int mode = (khw <= MCAP) ? ST_INNER_FAST : ST_INNER_MATVEC;
-        if (mode == ST_INNER_FAST) {
-          // z = hc - M r  with the rows M[w] = H^-1 c_w kept in LDS
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) zs[ax] = hcs[ax];
-          for (int w0 = 0; w0 < khw; w0 += 4) {
-            double mv[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int ax = 0; ax < 3; ++ax)
-                mv[u][ax] = (w0 + u < khw && lane < nst) ? Sb.M[w0 + u][3 * lane + ax] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double rv = readlane_f64(rw[0], (w0 + u) & 63);  // MCAP <= 64: slot lives in q = 0
-#pragma unroll
-              for (int ax = 0; ax < 3; ++ax) zs[ax] = __builtin_fma(-rv, mv[u][ax], zs[ax]);
-            }
-          }
-        } else {
-          // y = c_p - C_W r, gathered per stance slot, for the distributed mat-vec
-          for (int k = lane; k < NP; k += WAVE) Sb.y[k] = 0.0;
-          double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-#pragma unroll
-          for (int ty = 0; ty < 5; ++ty) {
-            // r of the working-set slot holding (lane, ty), fetched from its owner lane
-            const unsigned sl = aslot[ty];
-            double rv = 0.0;
-#pragma unroll
-            for (int q = 0; q < KW; ++q) {
-              const double cand = __shfl(rw[q], (int)(sl & 63u));
-              if ((int)(sl >> 6) == q) rv = cand;
-            }
-            if ((amask >> ty) & 1u) {
-              const double sg = (ty & 1) ? -mi : mi;
-              if (ty < 2) y0 -= sg * rv;
-              else if (ty < 4) y1 -= sg * rv;
-              y2 -= (ty < 4) ? rv : -rv;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
+        // z = H^-1 (c_p - C_W r) = hc - sum_w r_w H^-1 c_w , slot-major
+        double zs[3] = {hcs[0], hcs[1], hcs[2]};
+        for (int w = 0; w < khw; ++w) {
+          const int e = __builtin_amdgcn_readlane(pick<KW>(wcid, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
+          if (e < 0) continue;  // uniform
+          const double rv = readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
+          int j1, j2;
+          double a1, a2;
+          con_coefs(e, mi, j1, j2, a1, a2);
           if (lane < nst) {
-            Sb.y[3 * lane + 0] = y0;
-            Sb.y[3 * lane + 1] = y1;
-            Sb.y[3 * lane + 2] = y2;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane == 0) {
-            Sb.y[pj1] += pa1;
-            if (two) Sb.y[pj2] += pa2;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+              const int row = 3 * lane + ax;
+              const double hw = a1 * Hinv(row, j1) + (a2 != 0.0 ? a2 * Hinv(row, j2) : 0.0);
+              zs[ax] = __builtin_fma(-rv, hw, zs[ax]);
+            }
           }
         }
-        if (lane == 0) S.state = mode;
-      }
-      __syncthreads();
-      if (S.state == ST_INNER_MATVEC) {
-        // --- z = H^-1 y : distributed mat-vec on the register matrix
-        double acc = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < CW; ++jj) acc = __builtin_fma(a[jj], Sb.y[c * CW + jj], acc);
-        Sb.part[c][i] = acc;
-        __syncthreads();
-        if (engine && lane < nst) {
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            const int j = 3 * lane + ax;
-            zs[ax] = -(Sb.part[0][j] + Sb.part[1][j] + Sb.part[2][j] + Sb.part[3][j]);
-          }
-        }
-      }
-      if (engine) {
-        QMPC_TICK1(11);
+        if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
         // delta = c_p^T z, current violation of p, step lengths
-        const int psl = p_e / 5, pty = p_e - 5 * psl;
-        const int ax1 = pj1 - 3 * psl;  // axis of the first coefficient (2 for the f_max row)
         const double dloc = pa1 * (ax1 == 0 ? zs[0] : (ax1 == 1 ? zs[1] : zs[2])) + pa2 * zs[2];
         const double sloc = pa1 * (ax1 == 0 ? xs[0] : (ax1 == 1 ? xs[1] : xs[2])) + pa2 * xs[2] - p_rhs;
         const double delta = readlane_f64(dloc, psl);
@@ -806,164 +723,148 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
             }
           }
         }
-        const double t1 = wave_min_pos_f64(ratio);
+        double t1 = __builtin_inf();
         int l = -1;
-        if (t1 < __builtin_inf()) {
-          const unsigned long long m = __ballot(ratio == t1);
-          const int ll = __ffsll((long long)m) - 1;
-          l = ll + 64 * __builtin_amdgcn_readlane(lq, ll);
+        if (khw > 0) {
+          t1 = wave_min_pos_f64(ratio);
+          if (t1 < __builtin_inf()) {
+            const unsigned long long m = __ballot(ratio == t1);
+            const int ll = __ffsll((long long)m) - 1;
+            l = ll + 64 * __builtin_amdgcn_readlane(lq, ll);
+          }
         }
         const double t = (t2 <= t1) ? t2 : t1;
-        QMPC_TICK1(12);
         if (!(t < __builtin_inf())) {
-          if (lane == 0) {
-            S.status |= QMPC_DEV_ST_INFEASIBLE;
-            S.state = ST_DONE;
+          status |= QMPC_DEV_ST_INFEASIBLE;
+          done = true;
+          break;
+        }
+        if (!dep) {
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) xs[ax] = __builtin_fma(t, zs[ax], xs[ax]);
+        }
+#pragma unroll
+        for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
+        lp += t;
+        iters += 1;
+        if (t2 <= t1) {
+          // full step: constraint p joins the working set in a free slot
+          int qslot = -1;
+#pragma unroll
+          for (int q = 0; q < KW; ++q) {
+            const bool fr = (lane + 64 * q < KMAX) && (wcid[q] < 0);
+            const unsigned long long m = __ballot(fr);
+            if (qslot < 0 && m) qslot = 64 * q + __ffsll((long long)m) - 1;
           }
-        } else {
-          if (!dep) {
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) xs[ax] = __builtin_fma(t, zs[ax], xs[ax]);
+          if (qslot < 0) {
+            status |= QMPC_DEV_ST_WS_FULL;
+            done = true;
+            break;
           }
+          const int kn = (qslot + 1 > khw) ? qslot + 1 : khw;
+          const double dinv = rdelta;
+          // bordered-inverse update of S_W^-1 (free slots have r = 0):
+          //   S[a][b] += r_a r_b / delta ; S[q][a] = -r_a / delta ; S[q][q] = 1/delta
+          for (int h0 = 0; h0 < kn; h0 += 4) {
+            double old[KW][4];
 #pragma unroll
-          for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
-          lp += t;
-          iters += 1;
-          if (t2 <= t1) {
-            // full step: constraint p joins the working set in a free slot
-            int qslot = -1;
+            for (int q = 0; q < KW; ++q)
 #pragma unroll
-            for (int q = 0; q < KW; ++q) {
-              const bool fr = (lane + 64 * q < KMAX) && (wcid[q] < 0);
-              const unsigned long long m = __ballot(fr);
-              if (qslot < 0 && m) qslot = 64 * q + __ffsll((long long)m) - 1;
-            }
-            if (qslot < 0) {
-              if (lane == 0) {
-                S.status |= QMPC_DEV_ST_WS_FULL;
-                S.state = ST_DONE;
-              }
-            } else {
-              const int kn = (qslot + 1 > khw) ? qslot + 1 : khw;
-              const double dinv = rdelta;
-              // bordered-inverse update of S_W^-1 (free slots have r = 0):
-              //   S[a][b] += r_a r_b / delta ; S[q][a] = -r_a / delta ; S[q][q] = 1/delta
-              for (int h0 = 0; h0 < kn; h0 += 4) {
-                double old[KW][4];
-#pragma unroll
-                for (int q = 0; q < KW; ++q)
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    const int hi = h0 + u, lo = lane + 64 * q;
-                    old[q][u] = (hi < kn && lo <= hi) ? Sb.Sinv[hi * (hi + 1) / 2 + lo] : 0.0;
-                  }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const int hi = h0 + u;
-                  const double rhi = readlane_f64(pick<KW>(rw, (hi >> 6) < KW ? (hi >> 6) : 0), hi & 63);
-#pragma unroll
-                  for (int q = 0; q < KW; ++q) {
-                    const int lo = lane + 64 * q;
-                    if (hi < kn && lo <= hi) {
-                      double v;
-                      if (hi == qslot && lo == qslot) v = dinv;
-                      else if (hi == qslot) v = -rw[q] * dinv;
-                      else if (lo == qslot) v = -rhi * dinv;
-                      else v = __builtin_fma(rhi * dinv, rw[q], old[q][u]);
-                      Sb.Sinv[hi * (hi + 1) / 2 + lo] = v;
-                    }
-                  }
-                }
-              }
-              if (qslot < MCAP && lane < nst) {
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) Sb.M[qslot][3 * lane + ax] = hcs[ax];
+              for (int u = 0; u < 4; ++u) {
+                const int hi = h0 + u, lo = lane + 64 * q;
+                old[q][u] = (hi < kn && lo <= hi) ? Sb.Sinv[hi * (hi + 1) / 2 + lo] : 0.0;
               }
 #pragma unroll
-              for (int q = 0; q < KW; ++q)
-                if (lane + 64 * q == qslot) {
-                  wcid[q] = p_e;
-                  lam[q] = lp;
-                  rw[q] = 0.0;
-                }
-              if (lane == psl) {
-                amask |= (1u << pty);
-#pragma unroll
-                for (int ty = 0; ty < 5; ++ty)
-                  if (ty == pty) aslot[ty] = (unsigned)qslot;
-              }
-              khw = kn;
-              if (dbg_clk && tid == 0 && iters == 1) dbg_clk[13] = clock64();
-              select();  // next violated constraint, or DONE
-              if (dbg_clk && tid == 0 && iters == 1) dbg_clk[14] = clock64();
-            }
-          } else {
-            // partial step: the multiplier of slot l hit zero -> drop it.
-            //   S' = S - S[:,l] S[l,:] / S[l,l] on the other slots; row/col l is
-            //   only read here and zeroed afterwards, so in place is safe.
-            const double il = fast_rcp(Sb.Sinv[sym_idx(l, l)]);
-            for (int hi = 0; hi < khw; ++hi) {
-              if (hi == l) continue;
-              const double shl = Sb.Sinv[sym_idx(hi, l)] * il;
+            for (int u = 0; u < 4; ++u) {
+              const int hi = h0 + u;
+              const double rhi = readlane_f64(pick<KW>(rw, (hi >> 6) < KW ? (hi >> 6) : 0), hi & 63);
 #pragma unroll
               for (int q = 0; q < KW; ++q) {
                 const int lo = lane + 64 * q;
-                if (lo <= hi && lo != l) {
-                  const int idx = hi * (hi + 1) / 2 + lo;
-                  Sb.Sinv[idx] = __builtin_fma(-shl, Sb.Sinv[sym_idx(l, lo)], Sb.Sinv[idx]);
+                if (hi < kn && lo <= hi) {
+                  double v;
+                  if (hi == qslot && lo == qslot) v = dinv;
+                  else if (hi == qslot) v = -rw[q] * dinv;
+                  else if (lo == qslot) v = -rhi * dinv;
+                  else v = __builtin_fma(rhi * dinv, rw[q], old[q][u]);
+                  Sb.Sinv[hi * (hi + 1) / 2 + lo] = v;
                 }
               }
             }
-            __builtin_amdgcn_wave_barrier();
+          }
 #pragma unroll
-            for (int q = 0; q < KW; ++q) {
-              const int w = lane + 64 * q;
-              if (w < khw) Sb.Sinv[sym_idx(w, l)] = 0.0;
+          for (int q = 0; q < KW; ++q)
+            if (lane + 64 * q == qslot) {
+              wcid[q] = p_e;
+              lam[q] = lp;
+              rw[q] = 0.0;
             }
-            // the dropped constraint leaves its slot: clear lane-w and lane-sl state
-            const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, l >> 6), l & 63);
+          if (lane == psl) amask |= (1u << pty);
+          khw = kn;
+          if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
+          break;  // next violated constraint
+        }
+        // partial step: the multiplier of slot l hit zero -> drop it.
+        //   S' = S - S[:,l] S[l,:] / S[l,l] on the other slots; row/col l is
+        //   only read here and zeroed afterwards, so in place is safe.
+        const double il = fast_rcp(Sb.Sinv[sym_idx(l, l)]);
+        for (int hi = 0; hi < khw; ++hi) {
+          if (hi == l) continue;
+          const double shl = Sb.Sinv[sym_idx(hi, l)] * il;
 #pragma unroll
-            for (int q = 0; q < KW; ++q)
-              if (lane + 64 * q == l) {
-                wcid[q] = -1;
-                lam[q] = 0.0;
-                rw[q] = 0.0;
-              }
-            if (lane == de / 5) amask &= ~(1u << (de % 5));
-            if (lane == 0) S.state = ST_INNER_FAST;  // "continue"; the mode is set at the top of the pass
+          for (int q = 0; q < KW; ++q) {
+            const int lo = lane + 64 * q;
+            if (lo <= hi && lo != l) {
+              const int idx = hi * (hi + 1) / 2 + lo;
+              Sb.Sinv[idx] = __builtin_fma(-shl, Sb.Sinv[sym_idx(l, lo)], Sb.Sinv[idx]);
+            }
           }
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+          const int w = lane + 64 * q;
+          if (w < khw) Sb.Sinv[sym_idx(w, l)] = 0.0;
+        }
+        // the dropped constraint leaves its slot: clear lane-w and lane-sl state
+        const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, (l >> 6) < KW ? (l >> 6) : 0), l & 63);
+#pragma unroll
+        for (int q = 0; q < KW; ++q)
+          if (lane + 64 * q == l) {
+            wcid[q] = -1;
+            lam[q] = 0.0;
+            rw[q] = 0.0;
+          }
+        if (lane == de / 5) amask &= ~(1u << (de % 5));
       }
-      __syncthreads();
-      if (dbg_clk && tid == 0 && iters == 1) dbg_clk[15] = clock64();
-      const int stt = S.state;
-      if (stt == ST_DONE || stt == ST_NEXT) break;
+      if (done) break;
     }
-  }
-  QMPC_TICK(6);
+    QMPC_TICK(6);
 
-  // ------------------------------------------------------------ outputs
-  // get_solution(0..11): forces of the four feet at horizon step 0
-  // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685).
-  if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
-  __syncthreads();
-  if (engine && lane < nst) {
-    const int k = S.sidx[lane];
-    if (k < 4) {
+    // ---------------------------------------------------------- outputs
+    // get_solution(0..11): forces of the four feet at horizon step 0
+    // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685);
+    // feet in swing at step 0 read 0.
+    if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nst) {
+      const int k = S.sidx[lane];
+      if (k < 4) {
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xs[ax];
+        for (int ax = 0; ax < 3; ++ax) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xs[ax];
+      }
+      if (P.soln) {
+        double* so = P.soln + (size_t)rid * 12 * h + 3 * k;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) so[ax] = xs[ax];
+      }
     }
-    if (P.soln) {
-      double* so = P.soln + (size_t)rid * 12 * h + 3 * k;
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) so[ax] = xs[ax];
+    if (lane == 0) {
+      P.status[rid] = S.status | status;
+      if (P.iters) P.iters[rid] = iters;
     }
   }
-  if (tid == 0) {
-    P.status[rid] = S.status;
-    if (P.iters) P.iters[rid] = iters;
-  }
-  __syncthreads();
+  __syncthreads();  // the other waves wait here for the engine
   QMPC_TICK(7);
 }
 

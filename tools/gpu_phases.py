@@ -28,17 +28,10 @@ sel = it > 0
 if sel.any():
     print(f"  active-set cycles per iteration (blocks with it>0): {np.median(d[sel,5]/it[sel]):.0f}")
 
-f = c[:, 8:16]
-ok = (it > 0) & (f[:, 7] > 0)
+ok = (it > 0) & (c[:, 10] > 0)
 if ok.any():
-    lab = ["extract->hc loads", "r = Sinv d", "z", "delta/t1/t2", "x,lam,Sinv,M update", "select", "end barrier"]
-    df = np.diff(f[ok], axis=1)
-    pre = f[ok, 0] - c[ok, 5]
-    print(f"  first iteration detail (median cycles): sel+barrier+extract {np.median(pre):.0f}")
-    for k, nm in enumerate(lab):
-        print(f"     {nm:22s} {np.median(df[:, k]):8.0f}")
-
-print("  sweep pair k0=10 (tid 0): start->scalars+rcp %d | fma loop %d | fixup+write+barrier %d | whole pair %d" % tuple(np.median(x) for x in (c[:,9]-c[:,8], c[:,10]-c[:,9], c[:,11]-c[:,10], c[:,11]-c[:,8])))
+    print("  first AS iteration (median cycles): select+hc %d | d,r,z %d | step+Sinv update %d" % (
+        np.median(c[ok, 8] - c[ok, 5]), np.median(c[ok, 9] - c[ok, 8]), np.median(c[ok, 10] - c[ok, 9])))
 order = np.argsort(c[:, 0])
 early, late = order[: len(order) // 2], order[len(order) // 2:]
 print("  blocks by start time: early-half median total %.0f (sweep %.0f) | late-half median total %.0f (sweep %.0f)" % (
