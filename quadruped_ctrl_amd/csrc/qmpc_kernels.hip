@@ -218,12 +218,67 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   QMPC_TICK(0);
 
   // ------------------------------------------------------------ stage 0
-  // contact table -> compact stance list (SolverMPC.cpp:441-469 finds the same
-  // set by scanning for ub ~ 0 rows); plus everything that needs no LDS input.
+  // Every global load of the robot's record is issued up front (one memory
+  // latency for the whole stage); then: contact table -> compact stance list
+  // (SolverMPC.cpp:441-469 finds the same set by scanning for ub ~ 0 rows) and
+  // everything that needs no LDS input.
+  auto& Aa = S.u.aw.a;
+  auto& Sw = S.u.aw.w;
+  const int eidx0 = tid;                     // one tracking-error entry per thread (12h <= NT)
+  const bool e_thr = eidx0 < 12 * h;
+  const int ek = eidx0 / 12, erow = eidx0 - 12 * ek;
+  const int mt = tid % 36, mb = mt / 9, ml = (mt % 9) / 3, max_ = mt % 3;  // (foot, row, axis) of M_b / N_b
+  const int hh = h * h;
+  // ---- loads
+  const float g_yaw = P.yaw[rid];
+  const float g_xdrag = P.x_drag[(size_t)rid * P.x_drag_stride];
+  unsigned char g_gait = 0;
+  if (tid < nfs) g_gait = P.gait[(size_t)rid * nfs + tid];
+  float g_r0 = 0.f, g_r1 = 0.f, g_r2 = 0.f;
+  if (tid < 72) {  // r_feet(axis, foot) = r[axis*4 + foot], RobotState.cpp:25-27
+    const float* r = P.r + (size_t)rid * 12;
+    g_r0 = r[0 * 4 + mb];
+    g_r1 = r[1 * 4 + mb];
+    g_r2 = r[2 * 4 + mb];
+  }
+  float g_q[4] = {1.f, 0.f, 0.f, 0.f}, g_w[3] = {0.f, 0.f, 0.f}, g_v[3] = {0.f, 0.f, 0.f};
+  float g_p = 0.f, g_traj = 0.f, g_wt = 0.f;
+  if (e_thr) {
+    const float* q = P.q + (size_t)rid * 4;
+    const float* om = P.w + (size_t)rid * 3;
+    const float* v = P.v + (size_t)rid * 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g_q[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g_w[k] = om[k];
+      g_v[k] = v[k];
+    }
+    if (erow >= 3 && erow < 6) g_p = P.p[(size_t)rid * 3 + (erow - 3)];
+    g_traj = P.traj[(size_t)rid * 12 * h + eidx0];
+    g_wt = P.weights[(size_t)rid * P.weights_stride + erow];
+  }
+  float g_w12 = 0.f;
+  if (tid >= 96 && tid < 96 + 12) g_w12 = P.weights[(size_t)rid * P.weights_stride + (tid - 96)];
+  double g_coef = 0.0;
+  if (tid >= 112 && tid < 112 + 3 * 16 && ((tid - 112) % 16) < h) g_coef = P.coef[((tid - 112) / 16) * h + ((tid - 112) % 16)];
+  const double x_drag = (double)g_xdrag;
+  const bool drag = (x_drag != 0.0);
+  double g_ct0 = 0.0, g_ct4 = 0.0, g_ct1 = 0.0, g_ct5 = 0.0, g_ct8 = 0.0;
+  if (tid < hh) {  // h*h <= 256 == NT for RB = 1; larger classes loop below
+    g_ct0 = P.ctab[tid];
+    g_ct4 = P.ctab[4 * hh + tid];
+    if (drag) {
+      g_ct1 = P.ctab[1 * hh + tid];
+      g_ct5 = P.ctab[5 * hh + tid];
+      g_ct8 = P.ctab[8 * hh + tid];
+    }
+  }
+
+  // ---- stance list
   if (tid < WAVE) {
-    float fm = 0.f;
-    if (tid < nfs) fm = (float)P.gait[(size_t)rid * nfs + tid] * (float)P.f_max;  // :361
-    const bool st = !(fm < 0.01f && fm > -.01f);                                   // :64-67
+    const float fm = (float)g_gait * (float)P.f_max;  // :361
+    const bool st = !(fm < 0.01f && fm > -.01f);       // :64-67
     const unsigned long long mask = __ballot(st);
     const int pos = __popcll(mask & ((1ull << tid) - 1ull));
     if (st) {
@@ -238,26 +293,20 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   if (P.soln)  // q_soln is zero on swing feet (SolverMPC.cpp:545-551)
     for (int k = tid; k < 12 * h; k += NT) P.soln[(size_t)rid * 12 * h + k] = 0.0;
 
-  auto& Aa = S.u.aw.a;
-  auto& Sw = S.u.aw.w;
-  const double x_drag = (double)P.x_drag[(size_t)rid * P.x_drag_stride];
-  const bool drag = (x_drag != 0.0);
   const double inv_m = 1.0 / P.mass;
   {
     // yaw rotation (RobotState.cpp:30-35); float transcendentals like the reference
     float syf, cyf;
-    sincosf(P.yaw[rid], &syf, &cyf);
+    sincosf(g_yaw, &syf, &cyf);
     const double cy = cyf, sy = syf;
     if (tid < 72) {
       // M_b = I_w^-1 [r_b]x with I_w^-1 = R diag(1/I) R^T (closed form of
       // I_world.inverse(), SolverMPC.cpp:319,:247), N_b = R^T M_b.
-      // Thread (b, l, a): t = 9b + 3l + a.
-      const int t = tid % 36, b = t / 9, l = (t % 9) / 3, ax = t % 3;
+      const int b = mb, l = ml, ax = max_;
       const double ix = 1.0 / P.ibody[0], iy = 1.0 / P.ibody[1], iz = 1.0 / P.ibody[2];
       const double I00 = cy * cy * ix + sy * sy * iy, I01 = cy * sy * (ix - iy),
                    I11 = sy * sy * ix + cy * cy * iy;
-      const float* r = P.r + (size_t)rid * 12;  // r_feet(axis, foot) = r[axis*4 + foot], RobotState.cpp:25-27
-      const double rx = r[0 * 4 + b], ry = r[1 * 4 + b], rz = r[2 * 4 + b];
+      const double rx = g_r0, ry = g_r1, rz = g_r2;
       // column ax of [r]x  (cross_mat, SolverMPC.cpp:226-233)
       const double cm0 = (ax == 0) ? 0.0 : (ax == 1 ? -rz : ry);
       const double cm1 = (ax == 0) ? rz : (ax == 1 ? 0.0 : -rx);
@@ -272,22 +321,20 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         Aa.Nb[b][3 * l + ax] = (l == 0) ? (cy * m0 + sy * m1) : (l == 1 ? (-sy * m0 + cy * m1) : m2);
       }
     } else if (tid >= 96 && tid < 96 + 12) {
-      Aa.W[tid - 96] = (double)P.weights[(size_t)rid * P.weights_stride + (tid - 96)];
+      Aa.W[tid - 96] = (double)g_w12;
     } else if (tid >= 112 && tid < 112 + 3 * 16) {
-      const int k = tid - 112, pp = k / 16, d = k % 16;
-      if (d < h) Aa.coef[pp * 16 + d] = P.coef[pp * h + d];
+      Aa.coef[tid - 112] = g_coef;
     }
     // weighted tracking error of the free response at step k (k < h):
     //   e_k = W .* (x0 + A x0 t + A^2 x0 t^2/2 - xd_k),  t = (k+1) dt
     // ( = S (A_qp x0 - X_d), SolverMPC.cpp:399 ), closed form per state row.
-    for (int idx = tid; idx < 12 * h; idx += NT) {
-      const int k = idx / 12, row = idx - 12 * k;
-      const double t = (double)(k + 1) * P.dt;
+    if (e_thr) {
+      const int row = erow;
+      const double t = (double)(ek + 1) * P.dt;
       double val;
       if (row < 3) {
         // x0(0..2) = roll, pitch, yaw from the quaternion (SolverMPC.cpp:257-267, :318)
-        const float* q = P.q + (size_t)rid * 4;
-        const float w = q[0], x = q[1], y = q[2], z = q[3];
+        const float w = g_q[0], x = g_q[1], y = g_q[2], z = g_q[3];
         float ang;
         if (row == 0) {
           ang = atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z);
@@ -298,32 +345,27 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         } else {
           ang = atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z);
         }
-        const float* om = P.w + (size_t)rid * 3;
-        const double o0 = om[0], o1 = om[1], o2 = om[2];
+        const double o0 = g_w[0], o1 = g_w[1], o2 = g_w[2];
         const double rate = (row == 0) ? (cy * o0 + sy * o1) : (row == 1 ? (-sy * o0 + cy * o1) : o2);
         val = (double)ang + rate * t;  // Theta' = R_yaw^T omega
       } else if (row < 6) {
-        const float* v = P.v + (size_t)rid * 3;
-        val = (double)P.p[(size_t)rid * 3 + (row - 3)] + (double)v[row - 3] * t;
-        if (row == 5) val += 0.5 * (P.gravity + x_drag * (double)v[0]) * t * t;  // A(11,12), A(11,9)
+        val = (double)g_p + (double)(row == 3 ? g_v[0] : (row == 4 ? g_v[1] : g_v[2])) * t;
+        if (row == 5) val += 0.5 * (P.gravity + x_drag * (double)g_v[0]) * t * t;  // A(11,12), A(11,9)
       } else if (row < 9) {
-        val = (double)P.w[(size_t)rid * 3 + (row - 6)];
+        val = (double)(row == 6 ? g_w[0] : (row == 7 ? g_w[1] : g_w[2]));
       } else {
-        const float* v = P.v + (size_t)rid * 3;
-        val = (double)v[row - 9];
-        if (row == 11) val += (P.gravity + x_drag * (double)v[0]) * t;
+        val = (double)(row == 9 ? g_v[0] : (row == 10 ? g_v[1] : g_v[2]));
+        if (row == 11) val += (P.gravity + x_drag * (double)g_v[0]) * t;
       }
-      const double wt = (double)P.weights[(size_t)rid * P.weights_stride + row];
-      Aa.e[idx] = wt * (val - (double)P.traj[(size_t)rid * 12 * h + idx]);
+      Aa.e[eidx0] = (double)g_wt * (val - (double)g_traj);
     }
-    const int hh = h * h;
-    for (int idx = tid; idx < hh; idx += NT) {
-      Aa.ct0[idx] = P.ctab[idx];
-      Aa.ct4[idx] = P.ctab[4 * hh + idx];
+    if (tid < hh) {
+      Aa.ct0[tid] = g_ct0;
+      Aa.ct4[tid] = g_ct4;
       if (drag) {
-        Aa.ct1[idx] = P.ctab[1 * hh + idx];
-        Aa.ct5[idx] = P.ctab[5 * hh + idx];
-        Aa.ct8[idx] = P.ctab[8 * hh + idx];
+        Aa.ct1[tid] = g_ct1;
+        Aa.ct5[tid] = g_ct5;
+        Aa.ct8[tid] = g_ct8;
       }
     }
   }
