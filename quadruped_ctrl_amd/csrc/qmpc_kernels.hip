@@ -187,7 +187,10 @@ struct Smem {
     } aw;
     struct Slv {  // active-set solve (stage 5): the engine wave's working storage
       double Hp[C::NH];    // H^-1, packed lower triangle: (i,j), i >= j, at i(i+1)/2 + j
-      double Sinv[C::NS];  // (C_W^T H^-1 C_W)^-1, packed the same way
+      // pool: (C_W^T H^-1 C_W)^-1 packed the same way, growing from the front with
+      // the slot high-water mark; rows M[w] = H^-1 c_w (NP doubles each) from the
+      // back while they fit (beyond that they are recomputed from Hp)
+      double Sinv[C::NS];
     } b;
   } u;
 };
@@ -580,16 +583,17 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   }
   __syncthreads();
   const bool engine = tid < WAVE;
-  double xs[3] = {0.0, 0.0, 0.0};  // engine lane sl: forces of stance slot sl
-  double fmx = 0.0;                // its f_max
-  if (engine && lane < nst) {
+  double xv[RB];  // engine lane: x[lane + 64 q]
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      const int j = 3 * lane + ax;
-      xs[ax] = Sw.part[0][j] + Sw.part[1][j] + Sw.part[2][j] + Sw.part[3][j];
+  for (int q = 0; q < RB; ++q) xv[q] = 0.0;
+  if (engine) {
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int j = lane + 64 * q;
+      if (j < n) xv[q] = Sw.part[0][j] + Sw.part[1][j] + Sw.part[2][j] + Sw.part[3][j];
     }
-    fmx = S.fmaxk[lane];
   }
+  const double fmx = (engine && lane < nst) ? S.fmaxk[lane] : 0.0;  // f_max of stance slot `lane`
   __syncthreads();  // sweep storage (and the assembly storage under it) is dead: Slv may overwrite it
   if (i < n) {
     // opaque copies of the indices: keeps the compiler from carrying values that
@@ -611,9 +615,11 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   // ------------------------------------------------------------ stage 5
   // Goldfarb-Idnani dual active set on the explicit inverse, run by wave 0
   // alone: no block barrier inside the loop.  Engine state lives in registers:
-  //   lane = stance slot sl : x[3sl..3sl+2], working-set membership of its 5 rows
-  //   lane = working-set slot w (+64q): constraint id, multiplier, r_w
-  // and all matrix data comes from the packed H^-1 and S_W^-1 in LDS.
+  //   lane = variable index i (+64q)   : x_i, (H^-1 c_p)_i, z_i
+  //   lane = stance slot sl            : working-set membership of its 5 rows
+  //   lane = working-set slot w (+64q) : constraint id, multiplier, r_w
+  // Cross-lane traffic is DPP / readlane / bpermute; matrix data comes from the
+  // packed H^-1, S_W^-1 and the pooled rows H^-1 c_w in LDS.
   int iters = 0;
   if (engine) {
     const double mi = P.mu_inv;
@@ -624,11 +630,28 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       const int hi = r > cidx ? r : cidx, lo = r > cidx ? cidx : r;
       return Sb.Hp[hi * (hi + 1) / 2 + lo];
     };
+    // value of the index-major vector v at variable j (per-lane j): a bpermute per 64-block
+    auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+      double out = 0.0;
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const double cand = __shfl(v[q], j & 63);
+        if ((j >> 6) == q) out = cand;
+      }
+      return out;
+    };
+    // the same for a wave-uniform j
+    auto bcast = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+      return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
+    };
+    // row w of M = H^-1 C_W lives at the back of the pool while it does not collide with S_W^-1
+    auto m_row = [&](int w) __attribute__((always_inline)) { return &Sb.Sinv[C::NS - NP * (w + 1)]; };
 
-    unsigned amask = 0;  // bit ty: constraint (sl, ty) is in the working set
-    int wcid[KW];        // engine lane w: constraint id in slot w + 64 q, -1 = free
+    unsigned amask = 0;  // stance-slot lane: bit ty = constraint (sl, ty) is in the working set
+    int wcid[KW];        // working-slot lane: constraint id in slot w + 64 q, -1 = free
     double lam[KW], rw[KW];
     int khw = 0;         // high-water mark of used working-set slots (uniform)
+    int mvalid = 0;      // rows M[0..mvalid) are stored (uniform)
     int status = 0;
 #pragma unroll
     for (int q = 0; q < KW; ++q) {
@@ -641,15 +664,19 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       // ---- pick the most violated constraint outside the working set
       //      (normalised by its row norm); none -> optimal
       unsigned key = 0;
-      if (lane < nst) {
-        const double sv[5] = {(mi * xs[0] + xs[2]) * inv_fr, (-mi * xs[0] + xs[2]) * inv_fr,
-                              (mi * xs[1] + xs[2]) * inv_fr, (-mi * xs[1] + xs[2]) * inv_fr, fmx - xs[2]};
+      {
+        const int j0 = 3 * (lane < nst ? lane : 0);
+        const double x0 = gather(xv, j0), x1 = gather(xv, j0 + 1), x2 = gather(xv, j0 + 2);
+        if (lane < nst) {
+          const double sv[5] = {(mi * x0 + x2) * inv_fr, (-mi * x0 + x2) * inv_fr, (mi * x1 + x2) * inv_fr,
+                                (-mi * x1 + x2) * inv_fr, fmx - x2};
 #pragma unroll
-        for (int ty = 0; ty < 5; ++ty) {
-          if (!((amask >> ty) & 1u) && sv[ty] < -tol) {
-            // more negative -> larger float magnitude -> larger key; low 9 bits = id
-            const unsigned kk = (__float_as_uint((float)(-sv[ty])) & ~0x1FFu) | (unsigned)(5 * lane + ty);
-            key = kk > key ? kk : key;
+          for (int ty = 0; ty < 5; ++ty) {
+            if (!((amask >> ty) & 1u) && sv[ty] < -tol) {
+              // more negative -> larger float magnitude -> larger key; low 9 bits = id
+              const unsigned kk = (__float_as_uint((float)(-sv[ty])) & ~0x1FFu) | (unsigned)(5 * lane + ty);
+              key = kk > key ? kk : key;
+            }
           }
         }
       }
@@ -666,42 +693,35 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       double pa1, pa2;
       con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
       const bool two = (pa2 != 0.0);
-      const int ax1 = pj1 - 3 * psl;  // axis of the first coefficient (2 for the f_max row)
       const double p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
       if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
 
-      // hc = H^-1 c_p, slot-major: lane sl holds hc[3sl..3sl+2]
-      double hcs[3] = {0.0, 0.0, 0.0};
-      if (lane < nst) {
+      // hc = H^-1 c_p, index-major
+      double hc[RB];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          const int row = 3 * lane + ax;
-          hcs[ax] = pa1 * Hinv(row, pj1) + (two ? pa2 * Hinv(row, pj2) : 0.0);
-        }
+      for (int q = 0; q < RB; ++q) {
+        const int row = lane + 64 * q;
+        hc[q] = (row < n) ? pa1 * Hinv(row, pj1) + (two ? pa2 * Hinv(row, pj2) : 0.0) : 0.0;
       }
-      // c_p^T H^-1 c_p : both coefficients live in slot psl
-      const double hcn = readlane_f64(pa1 * (ax1 == 0 ? hcs[0] : (ax1 == 1 ? hcs[1] : hcs[2])) + pa2 * hcs[2], psl);
+      const double hcn = pa1 * bcast(hc, pj1) + (two ? pa2 * bcast(hc, pj2) : 0.0);  // c_p^T H^-1 c_p
+      // d = C_W^T H^-1 c_p does not change while p is being added (only r does)
+      double dw[KW];
+#pragma unroll
+      for (int q = 0; q < KW; ++q) {
+        int j1 = 0, j2 = 0;
+        double a1 = 0.0, a2 = 0.0;
+        if (wcid[q] >= 0) con_coefs(wcid[q], mi, j1, j2, a1, a2);
+        const double h1 = gather(hc, j1), h2 = gather(hc, j2);
+        dw[q] = a1 * h1 + a2 * h2;
+      }
       double lp = 0.0;  // multiplier of p
       bool done = false;
 
       // ---- inner loop: one pass per (partial or full) step
       while (true) {
-        // d = C_W^T H^-1 c_p (lane = working-set slot): 4 gathers from the packed inverse
-        double dw[KW];
+        // r = S_W^-1 d  (slots that were dropped hold d-contributions of 0 rows/cols)
 #pragma unroll
-        for (int q = 0; q < KW; ++q) {
-          dw[q] = 0.0;
-          if (wcid[q] >= 0) {
-            int j1, j2;
-            double a1, a2;
-            con_coefs(wcid[q], mi, j1, j2, a1, a2);
-            const double h1 = pa1 * Hinv(j1, pj1) + (two ? pa2 * Hinv(j1, pj2) : 0.0);
-            const double h2 = (a2 != 0.0) ? pa1 * Hinv(j2, pj1) + (two ? pa2 * Hinv(j2, pj2) : 0.0) : 0.0;
-            dw[q] = a1 * h1 + a2 * h2;
-          }
-          rw[q] = 0.0;
-        }
-        // r = S_W^-1 d
+        for (int q = 0; q < KW; ++q) rw[q] = 0.0;
         for (int v0 = 0; v0 < khw; v0 += 4) {
           double sv[KW][4];  // 4 entries of row w per lane, loaded back-to-back (one LDS latency)
 #pragma unroll
@@ -715,8 +735,10 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int v = v0 + u;  // slots >= khw hold d = 0
-            const double dv = readlane_f64(pick<KW>(dw, (v >> 6) < KW ? (v >> 6) : 0), v & 63);
+            const int v = v0 + u;
+            double dv = readlane_f64(pick<KW>(dw, (v >> 6) < KW ? (v >> 6) : 0), v & 63);
+            const int ev = __builtin_amdgcn_readlane(pick<KW>(wcid, (v >> 6) < KW ? (v >> 6) : 0), v & 63);
+            if (v >= khw || ev < 0) dv = 0.0;
 #pragma unroll
             for (int q = 0; q < KW; ++q) rw[q] = __builtin_fma(sv[q][u], dv, rw[q]);
           }
@@ -724,30 +746,47 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
 #pragma unroll
         for (int q = 0; q < KW; ++q)
           if (wcid[q] < 0) rw[q] = 0.0;
-        // z = H^-1 (c_p - C_W r) = hc - sum_w r_w H^-1 c_w , slot-major
-        double zs[3] = {hcs[0], hcs[1], hcs[2]};
-        for (int w = 0; w < khw; ++w) {
-          const int e = __builtin_amdgcn_readlane(pick<KW>(wcid, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
-          if (e < 0) continue;  // uniform
-          const double rv = readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
-          int j1, j2;
-          double a1, a2;
-          con_coefs(e, mi, j1, j2, a1, a2);
-          if (lane < nst) {
+        // z = H^-1 (c_p - C_W r) = hc - sum_w r_w (H^-1 c_w), index-major
+        double z[RB];
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-              const int row = 3 * lane + ax;
-              const double hw = a1 * Hinv(row, j1) + (a2 != 0.0 ? a2 * Hinv(row, j2) : 0.0);
-              zs[ax] = __builtin_fma(-rv, hw, zs[ax]);
+        for (int q = 0; q < RB; ++q) z[q] = hc[q];
+        {
+          const int wfast = khw < mvalid ? khw : mvalid;
+          for (int w0 = 0; w0 < wfast; w0 += 4) {  // stored rows: one load per lane and slot
+            double mv[4][RB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int q = 0; q < RB; ++q) mv[u][q] = (w0 + u < wfast) ? m_row(w0 + u)[lane + 64 * q] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int w = w0 + u;
+              const double rv = (w < wfast) ? readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63) : 0.0;
+#pragma unroll
+              for (int q = 0; q < RB; ++q) z[q] = __builtin_fma(-rv, mv[u][q], z[q]);
+            }
+          }
+          for (int w = wfast; w < khw; ++w) {  // rows that did not fit the pool: recompute from Hp
+            const int e = __builtin_amdgcn_readlane(pick<KW>(wcid, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
+            if (e < 0) continue;  // uniform
+            const double rv = readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
+            int j1, j2;
+            double a1, a2;
+            con_coefs(e, mi, j1, j2, a1, a2);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+              const int row = lane + 64 * q;
+              if (row < n) {
+                const double hw = a1 * Hinv(row, j1) + (a2 != 0.0 ? a2 * Hinv(row, j2) : 0.0);
+                z[q] = __builtin_fma(-rv, hw, z[q]);
+              }
             }
           }
         }
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
         // delta = c_p^T z, current violation of p, step lengths
-        const double dloc = pa1 * (ax1 == 0 ? zs[0] : (ax1 == 1 ? zs[1] : zs[2])) + pa2 * zs[2];
-        const double sloc = pa1 * (ax1 == 0 ? xs[0] : (ax1 == 1 ? xs[1] : xs[2])) + pa2 * xs[2] - p_rhs;
-        const double delta = readlane_f64(dloc, psl);
-        const double sp = readlane_f64(sloc, psl);
+        const double delta = pa1 * bcast(z, pj1) + (two ? pa2 * bcast(z, pj2) : 0.0);
+        const double sp = pa1 * bcast(xv, pj1) + (two ? pa2 * bcast(xv, pj2) : 0.0) - p_rhs;
         const bool dep = !(delta > 1e-12 * hcn);
         const double rdelta = fast_rcp(dep ? 1.0 : delta);
         const double t2 = dep ? __builtin_inf() : -sp * rdelta;
@@ -783,7 +822,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         }
         if (!dep) {
 #pragma unroll
-          for (int ax = 0; ax < 3; ++ax) xs[ax] = __builtin_fma(t, zs[ax], xs[ax]);
+          for (int q = 0; q < RB; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
         }
 #pragma unroll
         for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
@@ -804,6 +843,14 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
             break;
           }
           const int kn = (qslot + 1 > khw) ? qslot + 1 : khw;
+          // the packed S_W^-1 grows with the high-water mark: rows of M it would
+          // overwrite are given up first
+          {
+            const int room = (C::NS - kn * (kn + 1) / 2) / NP;  // rows of M that still fit behind it
+            const int want = (qslot == mvalid) ? mvalid + 1 : mvalid;
+            mvalid = want < room ? want : (mvalid < room ? mvalid : room);
+            if (mvalid < 0) mvalid = 0;
+          }
           const double dinv = rdelta;
           // bordered-inverse update of S_W^-1 (free slots have r = 0):
           //   S[a][b] += r_a r_b / delta ; S[q][a] = -r_a / delta ; S[q][q] = 1/delta
@@ -833,6 +880,10 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
                 }
               }
             }
+          }
+          if (qslot < mvalid) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) m_row(qslot)[lane + 64 * q] = hc[q];
           }
 #pragma unroll
           for (int q = 0; q < KW; ++q)
@@ -876,6 +927,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
             wcid[q] = -1;
             lam[q] = 0.0;
             rw[q] = 0.0;
+            dw[q] = 0.0;
           }
         if (lane == de / 5) amask &= ~(1u << (de % 5));
       }
@@ -889,16 +941,13 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
     // feet in swing at step 0 read 0.
     if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
     __builtin_amdgcn_wave_barrier();
-    if (lane < nst) {
-      const int k = S.sidx[lane];
-      if (k < 4) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xs[ax];
-      }
-      if (P.soln) {
-        double* so = P.soln + (size_t)rid * 12 * h + 3 * k;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) so[ax] = xs[ax];
+    for (int q = 0; q < RB; ++q) {
+      const int j = lane + 64 * q;
+      if (j < n) {
+        const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
+        if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xv[q];
+        if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
       }
     }
     if (lane == 0) {

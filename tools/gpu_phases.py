@@ -36,3 +36,8 @@ order = np.argsort(c[:, 0])
 early, late = order[: len(order) // 2], order[len(order) // 2:]
 print("  blocks by start time: early-half median total %.0f (sweep %.0f) | late-half median total %.0f (sweep %.0f)" % (
     np.median(tot[early]), np.median(d[early, 3]), np.median(tot[late]), np.median(d[late, 3])))
+end = c[:, 7] - c[:, 0].min()
+qs = [50, 90, 99, 99.9, 100]
+print("  block END time (cycles since first start) percentiles", {q: int(np.percentile(end, q)) for q in qs})
+print("  iters percentiles", {q: int(np.percentile(it, q)) for q in qs}, " AS cycles by iters:",
+      {int(k): int(np.median(d[it == k, 5])) for k in np.unique(it)[:16]})
