@@ -505,11 +505,11 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   // k0 % CW and +1, and are broadcast through a double-buffered pair of LDS
   // vectors (row k == column k by symmetry).  Every thread applies pivot k0 to
   // its copy of column k1 locally (c1' = c1 - c0 e/d0), so the second pivot
-  // needs no second broadcast:
-  //     a_ij <- a_ij - f0_i c0_j - f1_i c1'_j ,  f0 = c0/d0 , f1 = c1'/d1
-  //          = a_ij - (f0_i - f1_i g) c0_j - f1_i c1_j ,  g = e/d0 .
-  // Pivot-row trick: a_kj <- a_kj/d == a_kj - ((d-1)/d) c_j, i.e. the pivot
-  // rows use f = (d-1)/d and need no special casing in the update.
+  // needs no second broadcast.  With C = A[:, {k0,k1}] and P = A[{k0,k1},{k0,k1}]:
+  //     A <- A - F C^T ,  F = C P^-1 ;  pivot columns <- F ;  pivot block <- -P^-1
+  // i.e. two fma per element on the ORIGINAL columns.  Pivot rows need
+  // (P^-1 C^T); since a_kj == c_j they get it from the same update with
+  // F_k = I - P^-1, so the update has no row special-casing.
   bool notpd = false;
   {
     if (c == 0) {
@@ -527,36 +527,30 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           const int m = k0 >> 1;
           const double* cb0 = Sw.colbuf[m & 1][0];
           const double* cb1 = Sw.colbuf[m & 1][1];
-          double d0 = cb0[k0];
+          const double d0 = cb0[k0];
           const double e = cb0[k1];  // A[k1][k0]
           const double d1p = cb1[k1];
           const double c0i = cb0[i], c1i = cb1[i];
-          if (!(d0 > 1e-300)) {
-            notpd = true;
-            d0 = 1e-300;
-          }
-          const double dinv0 = fast_rcp(d0);
-          const double g = e * dinv0;
-          double d1 = __builtin_fma(-e, g, d1p);  // pivot k1 after pivot k0
-          if (!(d1 > 1e-300)) {
-            notpd = true;
-            d1 = 1e-300;
-          }
-          const double dinv1 = fast_rcp(d1);
+          // 2x2 pivot block P = [[d0, e], [e, d1p]] inverted through its determinant:
+          // ONE reciprocal on the critical path.  P^-1 = idet [[d1p, -e], [-e, d0]].
+          const double det = __builtin_fma(d0, d1p, -e * e);
+          notpd |= !(d0 > 0.0) | !(det > 0.0);
+          const double idet = fast_rcp(det);
+          const double i11 = d1p * idet, i01 = e * idet, i00 = d0 * idet;  // +-entries of P^-1
+          // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
+          const double fg0 = __builtin_fma(i11, c0i, -i01 * c1i);
+          const double fg1 = __builtin_fma(i00, c1i, -i01 * c0i);
           const bool p0 = (i == k0), p1 = (i == k1);
-          const double f0 = (p0 ? d0 - 1.0 : c0i) * dinv0;
-          const double c1pi = __builtin_fma(-f0, e, c1i);
-          const double f1 = (p1 ? d1 - 1.0 : c1pi) * dinv1;
-          // f0 c0_j + f1 c1'_j == (f0 - f1 g) c0_j + f1 c1_j : no per-element c1'
-          const double f0g = __builtin_fma(-f1, g, f0);
+          // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
+          const double u0 = fg0 + (p0 ? -i11 : (p1 ? i01 : 0.0));
+          const double u1 = fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0));
 #pragma unroll
           for (int jj = 0; jj < CW; ++jj)
-            a[jj] = __builtin_fma(-f1, cb1[c * CW + jj], __builtin_fma(-f0g, cb0[c * CW + jj], a[jj]));
+            a[jj] = __builtin_fma(-u1, cb1[c * CW + jj], __builtin_fma(-u0, cb0[c * CW + jj], a[jj]));
           if (c == kb) {
-            // column k0: f0 (pivot entry -1/d0) after pivot k0, then pivot k1 with
-            // A'[k1][k0] = g ; column k1: f1 (pivot entry -1/d1)
-            a[r0] = __builtin_fma(-f1, g, p0 ? -dinv0 : f0);
-            a[r1] = p1 ? -dinv1 : f1;
+            // pivot columns <- F, pivot block <- -P^-1
+            a[r0] = p0 ? -i11 : (p1 ? i01 : fg0);
+            a[r1] = p0 ? i01 : (p1 ? -i00 : fg1);
           }
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
