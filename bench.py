@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index")
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (override)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hint", action="store_true",
+                    help="do not tell the solver the workload's max stance foot-steps (launch every size class)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,6 +113,9 @@ def main():
 
     mpc = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=16)
     mpc.setup(b["dt"], h, b["mu"], b["f_max"])
+    max_stance = int((b["gait"] != 0).sum(1).max())
+    if not args.no_hint:
+        mpc.set_max_stance(max_stance)     # the caller built the contact tables, it knows their bound
     d = mpc.upload(b)
     o = mpc.alloc_outputs(per_gpu, full=False, iters=True)
     inp, out = mpc.make_args(d, o)
@@ -168,7 +173,8 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{args.config}]: batch={per_gpu} robots/GPU, "
                                    f"horizon={h}, mean reduced QP size {3.0 * nst.mean():.1f} vars",
                        "batch_per_gpu": per_gpu, "horizon": h, "sharding": f"independent robots x{world}",
-                       "mean_active_set_iters": float(iters.mean()), "failed": n_fail},
+                       "mean_active_set_iters": float(iters.mean()), "failed": n_fail,
+                       "max_stance_hint": (0 if args.no_hint else max_stance)},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "qmpc_solve_kernel<1>", "kernel_ms_hip_events": step_ms_ev,

@@ -106,6 +106,14 @@ int qmpc_set_robot(qmpc_handle h, double mass, const double ibody_diag[3],
  * SolverMPC.cpp:435) and the constraint-violation tolerance [N]. */
 int qmpc_settings(qmpc_handle h, int max_iter, double tol);
 
+/* Optional size hint.  The kernels are specialised by reduced problem size
+ * n_r = 3 * (stance foot-steps in the horizon) <= 64 / 128 / 192; without a
+ * hint every class that the horizon allows is launched (the unused ones exit
+ * at once).  A caller that knows its contact tables (e.g. trot: 2 feet x h)
+ * states the bound and the larger classes are skipped; a robot that exceeds
+ * it is reported with QMPC_ST_WS_FULL instead of being solved.  0 = no hint. */
+int qmpc_set_max_stance(qmpc_handle h, int max_stance_footsteps);
+
 /* Solve `batch` independent MPC problems.  All pointers are DEVICE pointers
  * valid on the handle's device; the call only enqueues work on `stream`
  * (a hipStream_t, NULL = default stream) and returns; results are readable

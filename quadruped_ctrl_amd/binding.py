@@ -17,7 +17,7 @@ ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL = 1, 2, 4, 8
 EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
-           "qmpc_set_debug_clock"]
+           "qmpc_set_debug_clock", "qmpc_set_max_stance"]
 
 
 class Inputs(C.Structure):
@@ -60,6 +60,7 @@ def load_library():
         lib.qmpc_set_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
+        lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
         _lib = lib
     return _lib
 
@@ -114,6 +115,10 @@ class BatchedConvexMPC:
     def set_robot(self, mass, ibody, gravity):
         arr = (C.c_double * 3)(*ibody)
         self._check(self.lib.qmpc_set_robot(self.h, mass, arr, gravity), "qmpc_set_robot")
+
+    def set_max_stance(self, max_stance_footsteps):
+        """Caller's bound on stance foot-steps per robot (0 = unknown)."""
+        self._check(self.lib.qmpc_set_max_stance(self.h, int(max_stance_footsteps)), "qmpc_set_max_stance")
 
     def settings(self, max_iter=1000, tol=1e-9):
         self._check(self.lib.qmpc_settings(self.h, max_iter, tol), "qmpc_settings")

@@ -31,7 +31,9 @@ struct qmpc_ctx {
   double tol = 1e-9;
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
   int* d_lists = nullptr;      // [2][max_batch] robot ids for classes 2 and 3
-  int* d_counts = nullptr;     // [4]: list counts (classes 2,3) and exit tickets; self-re-arming
+  int* d_counts = nullptr;     // [2 sets][2]: list lengths of classes 2,3, ping-ponged between calls
+  unsigned call_no = 0;
+  int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
   long long* dbg_clk = nullptr;
@@ -161,6 +163,12 @@ int qmpc_settings(qmpc_handle c, int max_iter, double tol) {
   return QMPC_OK;
 }
 
+int qmpc_set_max_stance(qmpc_handle c, int max_stance_footsteps) {
+  if (!c || max_stance_footsteps < 0) return QMPC_ERR_ARG;
+  c->max_stance = max_stance_footsteps;
+  return QMPC_OK;
+}
+
 int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_H = H_dev;
@@ -221,27 +229,36 @@ int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outpu
   // size classes: n_r = 3 * stance foot-steps <= 64 / 128 / 192
   const int nmax = 12 * h;
   const int nclass = nmax <= 64 ? 1 : (nmax <= 128 ? 2 : 3);
+  // a caller that knows its gaits can bound the reduced size (qmpc_set_max_stance):
+  // larger classes are then not even launched; violators are flagged WS_FULL
+  int nclass_eff = nclass;
+  if (c->max_stance > 0) {
+    const int nb = 3 * c->max_stance;
+    const int hc = nb <= 64 ? 1 : (nb <= 128 ? 2 : 3);
+    if (hc < nclass_eff) nclass_eff = hc;
+  }
   int* list2 = c->d_lists;
   int* list3 = c->d_lists + c->max_batch;
-  int* cnt2 = c->d_counts;
-  int* cnt3 = c->d_counts + 1;
+  const unsigned set = c->call_no & 1u;
+  c->call_no++;
+  int* cnt = c->d_counts + 2 * set;             // this call's counters
+  int* cnt_next = c->d_counts + 2 * (set ^ 1u); // cleared by this call's class-1 kernel
   // class 1: one workgroup per robot; larger robots are appended to list2
-  P.list = nullptr; P.count = nullptr; P.done = nullptr;
-  P.next_list = nclass > 1 ? list2 : nullptr;
-  P.next_count = nclass > 1 ? cnt2 : nullptr;
+  P.list = nullptr; P.count = nullptr; P.clear_counts = cnt_next;
+  P.next_list = nclass_eff > 1 ? list2 : nullptr;
+  P.next_count = nclass_eff > 1 ? cnt : nullptr;
   HIP_TRY(c, qmpc_launch(1, &P, batch, stream));
-  // classes 2, 3: persistent stride over the deferred lists (usually empty)
-  const int pgrid = batch < 512 ? batch : 512;
-  if (nclass > 1) {
-    P.list = list2; P.count = cnt2; P.done = c->d_counts + 2;
-    P.next_list = nclass > 2 ? list3 : nullptr;
-    P.next_count = nclass > 2 ? cnt3 : nullptr;
-    HIP_TRY(c, qmpc_launch(2, &P, pgrid, stream));
+  P.clear_counts = nullptr;
+  if (nclass_eff > 1) {
+    P.list = list2; P.count = cnt;
+    P.next_list = nclass_eff > 2 ? list3 : nullptr;
+    P.next_count = nclass_eff > 2 ? cnt + 1 : nullptr;
+    HIP_TRY(c, qmpc_launch(2, &P, batch, stream));
   }
-  if (nclass > 2) {
-    P.list = list3; P.count = cnt3; P.done = c->d_counts + 3;
+  if (nclass_eff > 2) {
+    P.list = list3; P.count = cnt + 1;
     P.next_list = nullptr; P.next_count = nullptr;
-    HIP_TRY(c, qmpc_launch(3, &P, pgrid < 256 ? pgrid : 256, stream));
+    HIP_TRY(c, qmpc_launch(3, &P, batch, stream));
   }
   return QMPC_OK;
 }

@@ -48,8 +48,8 @@ struct QmpcParams {
   double tol;
   // work lists: robots handed from one size class to the next
   const int* list;   // nullptr: robot = blockIdx.x
-  int* count;        // entries in `list`; re-armed to 0 by the last workgroup
-  int* done;         // workgroup exit ticket for that re-arming
+  int* count;        // entries in `list`
+  int* clear_counts; // class-1 kernel: the two counters of the NEXT call's set, zeroed here
   int* next_list;    // nullptr: no larger class available
   int* next_count;
   // debug dump (nullptr = off)

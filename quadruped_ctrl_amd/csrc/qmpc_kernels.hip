@@ -545,8 +545,11 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
           const double u0 = fg0 + (p0 ? -i11 : (p1 ? i01 : 0.0));
           const double u1 = fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0));
 #pragma unroll
-          for (int jj = 0; jj < CW; ++jj)
+          for (int jj = 0; jj < CW; ++jj) {
             a[jj] = __builtin_fma(-u1, cb1[c * CW + jj], __builtin_fma(-u0, cb0[c * CW + jj], a[jj]));
+            if constexpr (RB >= 3)  // 96 matrix registers: keep the column loads from being hoisted wholesale
+              if ((jj & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+          }
           if (c == kb) {
             // pivot columns <- F, pivot block <- -P^-1
             a[r0] = p0 ? -i11 : (p1 ? i01 : fg0);
@@ -956,32 +959,25 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
 }  // namespace
 
 // Class 1 (RB == 1): one workgroup per robot, robot = blockIdx.x.
-// Classes 2, 3: a persistent stride over the list of robots the previous class
-// deferred (usually empty).
+// Classes 2, 3: workgroup b takes entry b of the list of robots the previous
+// class deferred (grid = batch; workgroups past the list length exit at once).
+// The list counters are ping-ponged between consecutive solve calls: the
+// class-1 kernel of call N clears the set that call N+1 will use, so no memset
+// and no host round trip is needed.
 template <int RB>
 __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void qmpc_solve_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  int rid = (int)blockIdx.x;
+  if constexpr (RB == 1) {
+    if (blockIdx.x == 0 && threadIdx.x < 2 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+  } else {
+    if ((int)blockIdx.x >= *P.count) return;  // uniform
+    rid = P.list[blockIdx.x];
+  }
   if (threadIdx.x == 0) S.par = P;
   __syncthreads();
-  if constexpr (RB == 1) {
-    solve_one<RB>((int)blockIdx.x, S);
-  } else {
-    const int cnt = *S.par.count;
-#pragma unroll 1
-    for (int it = blockIdx.x; it < cnt; it += gridDim.x) solve_one<RB>(S.par.list[it], S);
-    // the last workgroup re-arms the list counter, so no memset has to precede
-    // the next solve call
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const int done = atomicAdd(S.par.done, 1);
-      if (done == (int)gridDim.x - 1) {
-        *S.par.count = 0;
-        *S.par.done = 0;
-        __threadfence();
-      }
-    }
-  }
+  solve_one<RB>(rid, S);
 }
 
 extern "C" size_t qmpc_smem_bytes(int rb) {
