@@ -250,3 +250,26 @@ def test_reference_shim_single_robot():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_size_hint(mpc_factory):
+    """qmpc_set_max_stance: a correct bound changes nothing; robots above the
+    bound are reported (QMPC_ST_WS_FULL), not silently mis-solved."""
+    b = W.make_config(4, batch=200)                 # n_r from 3*8 to 3*30: classes 1 and 2
+    m = mpc_factory(b)
+    base = m.solve(b, full=True)
+    nst = (b["gait"] != 0).sum(1)
+    m.set_max_stance(int(nst.max()))
+    ok = m.solve(b, full=True)
+    assert np.array_equal(ok["grf"], base["grf"]) and (ok["status"] == 0).all()
+    m.set_max_stance(21)                             # only class 1 (n_r <= 63) is launched
+    cut = m.solve(b, full=True)
+    big = nst > 21
+    assert big.any() and (~big).any()
+    assert np.all(cut["status"][big] == 8) and np.all(cut["status"][~big] == 0)
+    assert np.array_equal(cut["grf"][~big], base["grf"][~big])
+    m.set_max_stance(0)
+    again = m.solve(b, full=True)                    # back to all classes; lists re-arm themselves
+    assert np.array_equal(again["grf"], base["grf"])
+    for _ in range(3):                               # repeated calls reuse the ping-ponged counters
+        assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
