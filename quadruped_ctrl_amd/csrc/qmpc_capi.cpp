@@ -217,6 +217,8 @@ int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outpu
   P.f_max = c->f_max;
   P.mass = c->mass;
   for (int k = 0; k < 3; ++k) P.ibody[k] = c->ibody[k];
+  P.inv_mass = 1.0 / c->mass;
+  for (int k = 0; k < 3; ++k) P.inv_ibody[k] = 1.0 / c->ibody[k];
   P.gravity = c->gravity;
   P.coef = c->d_tables;
   P.ctab = c->d_tables + 3 * h;

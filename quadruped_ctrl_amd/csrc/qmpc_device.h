@@ -38,6 +38,7 @@ struct QmpcParams {
   int batch, horizon;
   double dt, mu_inv, inv_fr_norm, f_max;
   double mass, ibody[3], gravity;
+  double inv_mass, inv_ibody[3];  // host-side reciprocals (no fp64 divisions in the kernel prologue)
   // batch-constant tables built at qmpc_setup():
   //   coef[p][d]   p<3, d<h     dt, (2d+1)dt^2/2, ((d+1)^3-d^3)dt^3/6
   //   ctab[pq][i][j] pq<9       sum_{k>=max(i,j)} coef_p(k-i) coef_q(k-j)

@@ -207,17 +207,17 @@ struct Smem {
   } while (0)
 
 template <int RB>
-__device__ void solve_one(const int rid, Smem<RB>& S) {
+__device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW;
-  const QmpcParams& P = S.par;
+  const QmpcParams& P = S.par;  // parked copy: everything after stage 0
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int i = tid % NP;  // matrix row owned by this thread
   const int c = tid / NP;  // column group (0..3): columns c*CW .. c*CW+CW-1
-  const int h = P.horizon;
+  const int h = PK.horizon;
   const int nfs = 4 * h;   // foot-steps in the horizon (<= 64)
-  long long* dbg_clk = P.dbg_clk ? P.dbg_clk + (size_t)rid * 16 : nullptr;
+  long long* dbg_clk = PK.dbg_clk ? PK.dbg_clk + (size_t)rid * 16 : nullptr;
   QMPC_TICK(0);
 
   // ------------------------------------------------------------ stage 0
@@ -233,13 +233,13 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   const int mt = tid % 36, mb = mt / 9, ml = (mt % 9) / 3, max_ = mt % 3;  // (foot, row, axis) of M_b / N_b
   const int hh = h * h;
   // ---- loads
-  const float g_yaw = P.yaw[rid];
-  const float g_xdrag = P.x_drag[(size_t)rid * P.x_drag_stride];
+  const float g_yaw = PK.yaw[rid];
+  const float g_xdrag = PK.x_drag[(size_t)rid * PK.x_drag_stride];
   unsigned char g_gait = 0;
-  if (tid < nfs) g_gait = P.gait[(size_t)rid * nfs + tid];
+  if (tid < nfs) g_gait = PK.gait[(size_t)rid * nfs + tid];
   float g_r0 = 0.f, g_r1 = 0.f, g_r2 = 0.f;
   if (tid < 72) {  // r_feet(axis, foot) = r[axis*4 + foot], RobotState.cpp:25-27
-    const float* r = P.r + (size_t)rid * 12;
+    const float* r = PK.r + (size_t)rid * 12;
     g_r0 = r[0 * 4 + mb];
     g_r1 = r[1 * 4 + mb];
     g_r2 = r[2 * 4 + mb];
@@ -247,9 +247,9 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
   float g_q[4] = {1.f, 0.f, 0.f, 0.f}, g_w[3] = {0.f, 0.f, 0.f}, g_v[3] = {0.f, 0.f, 0.f};
   float g_p = 0.f, g_traj = 0.f, g_wt = 0.f;
   if (e_thr) {
-    const float* q = P.q + (size_t)rid * 4;
-    const float* om = P.w + (size_t)rid * 3;
-    const float* v = P.v + (size_t)rid * 3;
+    const float* q = PK.q + (size_t)rid * 4;
+    const float* om = PK.w + (size_t)rid * 3;
+    const float* v = PK.v + (size_t)rid * 3;
 #pragma unroll
     for (int k = 0; k < 4; ++k) g_q[k] = q[k];
 #pragma unroll
@@ -257,30 +257,35 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       g_w[k] = om[k];
       g_v[k] = v[k];
     }
-    if (erow >= 3 && erow < 6) g_p = P.p[(size_t)rid * 3 + (erow - 3)];
-    g_traj = P.traj[(size_t)rid * 12 * h + eidx0];
-    g_wt = P.weights[(size_t)rid * P.weights_stride + erow];
+    if (erow >= 3 && erow < 6) g_p = PK.p[(size_t)rid * 3 + (erow - 3)];
+    g_traj = PK.traj[(size_t)rid * 12 * h + eidx0];
+    g_wt = PK.weights[(size_t)rid * PK.weights_stride + erow];
   }
   float g_w12 = 0.f;
-  if (tid >= 96 && tid < 96 + 12) g_w12 = P.weights[(size_t)rid * P.weights_stride + (tid - 96)];
+  if (tid >= 96 && tid < 96 + 12) g_w12 = PK.weights[(size_t)rid * PK.weights_stride + (tid - 96)];
   double g_coef = 0.0;
-  if (tid >= 112 && tid < 112 + 3 * 16 && ((tid - 112) % 16) < h) g_coef = P.coef[((tid - 112) / 16) * h + ((tid - 112) % 16)];
+  if (tid >= 112 && tid < 112 + 3 * 16 && ((tid - 112) % 16) < h) g_coef = PK.coef[((tid - 112) / 16) * h + ((tid - 112) % 16)];
   const double x_drag = (double)g_xdrag;
   const bool drag = (x_drag != 0.0);
   double g_ct0 = 0.0, g_ct4 = 0.0, g_ct1 = 0.0, g_ct5 = 0.0, g_ct8 = 0.0;
   if (tid < hh) {  // h*h <= 256 == NT for RB = 1; larger classes loop below
-    g_ct0 = P.ctab[tid];
-    g_ct4 = P.ctab[4 * hh + tid];
+    g_ct0 = PK.ctab[tid];
+    g_ct4 = PK.ctab[4 * hh + tid];
     if (drag) {
-      g_ct1 = P.ctab[1 * hh + tid];
-      g_ct5 = P.ctab[5 * hh + tid];
-      g_ct8 = P.ctab[8 * hh + tid];
+      g_ct1 = PK.ctab[1 * hh + tid];
+      g_ct5 = PK.ctab[5 * hh + tid];
+      g_ct8 = PK.ctab[8 * hh + tid];
     }
   }
 
+  if (dbg_clk && tid == 0) {
+    float sink = g_yaw + g_traj + (float)g_gait + (float)g_ct0;
+    asm volatile("" ::"v"(sink));
+    dbg_clk[11] = clock64();
+  }
   // ---- stance list
   if (tid < WAVE) {
-    const float fm = (float)g_gait * (float)P.f_max;  // :361
+    const float fm = (float)g_gait * (float)PK.f_max;  // :361
     const bool st = !(fm < 0.01f && fm > -.01f);       // :64-67
     const unsigned long long mask = __ballot(st);
     const int pos = __popcll(mask & ((1ull << tid) - 1ull));
@@ -293,10 +298,10 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       S.status = 0;
     }
   }
-  if (P.soln)  // q_soln is zero on swing feet (SolverMPC.cpp:545-551)
-    for (int k = tid; k < 12 * h; k += NT) P.soln[(size_t)rid * 12 * h + k] = 0.0;
+  if (PK.soln)  // q_soln is zero on swing feet (SolverMPC.cpp:545-551)
+    for (int k = tid; k < 12 * h; k += NT) PK.soln[(size_t)rid * 12 * h + k] = 0.0;
 
-  const double inv_m = 1.0 / P.mass;
+  const double inv_m = PK.inv_mass;
   {
     // yaw rotation (RobotState.cpp:30-35); float transcendentals like the reference
     float syf, cyf;
@@ -306,7 +311,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       // M_b = I_w^-1 [r_b]x with I_w^-1 = R diag(1/I) R^T (closed form of
       // I_world.inverse(), SolverMPC.cpp:319,:247), N_b = R^T M_b.
       const int b = mb, l = ml, ax = max_;
-      const double ix = 1.0 / P.ibody[0], iy = 1.0 / P.ibody[1], iz = 1.0 / P.ibody[2];
+      const double ix = PK.inv_ibody[0], iy = PK.inv_ibody[1], iz = PK.inv_ibody[2];
       const double I00 = cy * cy * ix + sy * sy * iy, I01 = cy * sy * (ix - iy),
                    I11 = sy * sy * ix + cy * cy * iy;
       const double rx = g_r0, ry = g_r1, rz = g_r2;
@@ -333,7 +338,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
     // ( = S (A_qp x0 - X_d), SolverMPC.cpp:399 ), closed form per state row.
     if (e_thr) {
       const int row = erow;
-      const double t = (double)(ek + 1) * P.dt;
+      const double t = (double)(ek + 1) * PK.dt;
       double val;
       if (row < 3) {
         // x0(0..2) = roll, pitch, yaw from the quaternion (SolverMPC.cpp:257-267, :318)
@@ -353,12 +358,12 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
         val = (double)ang + rate * t;  // Theta' = R_yaw^T omega
       } else if (row < 6) {
         val = (double)g_p + (double)(row == 3 ? g_v[0] : (row == 4 ? g_v[1] : g_v[2])) * t;
-        if (row == 5) val += 0.5 * (P.gravity + x_drag * (double)g_v[0]) * t * t;  // A(11,12), A(11,9)
+        if (row == 5) val += 0.5 * (PK.gravity + x_drag * (double)g_v[0]) * t * t;  // A(11,12), A(11,9)
       } else if (row < 9) {
         val = (double)(row == 6 ? g_w[0] : (row == 7 ? g_w[1] : g_w[2]));
       } else {
         val = (double)(row == 9 ? g_v[0] : (row == 10 ? g_v[1] : g_v[2]));
-        if (row == 11) val += (P.gravity + x_drag * (double)g_v[0]) * t;
+        if (row == 11) val += (PK.gravity + x_drag * (double)g_v[0]) * t;
       }
       Aa.e[eidx0] = (double)g_wt * (val - (double)g_traj);
     }
@@ -372,6 +377,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       }
     }
   }
+  if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
   __syncthreads();  // ---- barrier 1
   QMPC_TICK(1);
   const int nst = S.nst;
@@ -450,6 +456,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
     Sw.g[tid] = gv;
   }
 
+  if (dbg_clk && tid == 0) dbg_clk[13] = clock64();
   double a[CW];
   {
     int si = 0, u = 0, ai = 0;
@@ -461,34 +468,53 @@ __device__ void solve_one(const int rid, Smem<RB>& S) {
       u = 3 * (ki & 3) + ai;
     }
     const double dm2 = x_drag * inv_m * inv_m;
-    // column j = c*CW + jj walks stance slots; (slot, axis) advance incrementally
-    int cslot = (c * CW) / 3, cax = (c * CW) % 3;
+    // the CW columns of this thread walk at most CW/3 + 2 stance slots: fetch
+    // their foot-step ids in one batch, then the table / E loads in groups of 4
+    constexpr int NSL = CW / 3 + 2;
+    const int cslot0 = (c * CW) / 3, cax0 = (c * CW) % 3;
+    int kjs[NSL];
+#pragma unroll
+    for (int q = 0; q < NSL; ++q) kjs[q] = (cslot0 + q < nst) ? (int)S.sidx[cslot0 + q] : 0;
+    // branch-free element loop (indices are always in range: out-of-range rows /
+    // columns read slot 0 and are overwritten by the padding select), so the LDS
+    // loads of a group of elements are in flight together.  The (slot, axis) walk
+    // of the columns is compile-time once the start axis (wave-uniform) is fixed.
+    auto fill = [&](auto cax0c) __attribute__((always_inline)) {
+      constexpr int CAX0 = decltype(cax0c)::value;
+#pragma unroll
+      for (int jj = 0; jj < CW; ++jj) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int kj = kjs[(CAX0 + jj) / 3], cax = (CAX0 + jj) % 3;
+        const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + cax;
+        // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
+        a[jj] = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
+        if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+      }
+      if (drag) {  // uniform
+        // E_01 / E_12 couple (z of foot-step i, x of foot-step j); E_10 / E_21 the
+        // transposed pair (C_qp[i][j] == C_pq[j][i]); E_22 couples x with x.
+        const double w11 = Aa.W[11] * dm2, w5 = Aa.W[5] * dm2, w5x = Aa.W[5] * (x_drag * dm2);
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) {
+          const int kj = kjs[(CAX0 + jj) / 3], cax = (CAX0 + jj) % 3;
+          const int sj = kj >> 2, cidx = si * h + sj, tidx = sj * h + si;
+          double add = 0.0;
+          if (ai == 2 && cax == 0) add = Aa.ct1[cidx] * w11 + Aa.ct5[cidx] * w5;
+          if (ai == 0 && cax == 2) add = Aa.ct1[tidx] * w11 + Aa.ct5[tidx] * w5;
+          if (ai == 0 && cax == 0) add = Aa.ct8[cidx] * w5x;
+          a[jj] += add;
+        }
+      }
+    };
+    if (cax0 == 0) fill(std::integral_constant<int, 0>{});
+    else if (cax0 == 1) fill(std::integral_constant<int, 1>{});
+    else fill(std::integral_constant<int, 2>{});
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) {
       const int j = c * CW + jj;
-      double val = (i == j) ? 1.0 : 0.0;  // identity padding
-      if (rowok && j < n) {
-        const int kj = S.sidx[cslot];
-        const int sj = kj >> 2, cidx = si * h + sj, eidx = u * 12 + 3 * (kj & 3) + cax;
-        // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
-        double acc = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
-        if (drag) {
-          // E_01 / E_12 couple (z of foot-step i, x of foot-step j); E_10 / E_21 the
-          // transposed pair (C_qp[i][j] == C_pq[j][i]); E_22 couples x with x.
-          const int tidx = sj * h + si;
-          if (ai == 2 && cax == 0) acc += (Aa.ct1[cidx] * Aa.W[11] + Aa.ct5[cidx] * Aa.W[5]) * dm2;
-          if (ai == 0 && cax == 2) acc += (Aa.ct1[tidx] * Aa.W[11] + Aa.ct5[tidx] * Aa.W[5]) * dm2;
-          if (ai == 0 && cax == 0) acc += Aa.ct8[cidx] * Aa.W[5] * (x_drag * dm2);
-        }
-        if (i == j) acc += alpha;
-        val = 2.0 * acc;
-      }
-      a[jj] = val;
-      if (++cax == 3) {
-        cax = 0;
-        ++cslot;
-      }
-      if ((jj & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+      const double v = 2.0 * (a[jj] + ((i == j) ? alpha : 0.0));
+      a[jj] = (rowok && j < n) ? v : ((i == j) ? 1.0 : 0.0);  // identity padding
     }
   }
   if (P.dbg_H) {
@@ -975,9 +1001,8 @@ __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void q
     if ((int)blockIdx.x >= *P.count) return;  // uniform
     rid = P.list[blockIdx.x];
   }
-  if (threadIdx.x == 0) S.par = P;
-  __syncthreads();
-  solve_one<RB>(rid, S);
+  if (threadIdx.x == 0) S.par = P;  // visible to all after the first barrier inside solve_one
+  solve_one<RB>(rid, S, P);
 }
 
 extern "C" size_t qmpc_smem_bytes(int rb) {

@@ -41,3 +41,6 @@ qs = [50, 90, 99, 99.9, 100]
 print("  block END time (cycles since first start) percentiles", {q: int(np.percentile(end, q)) for q in qs})
 print("  iters percentiles", {q: int(np.percentile(it, q)) for q in qs}, " AS cycles by iters:",
       {int(k): int(np.median(d[it == k, 5])) for k in np.unique(it)[:16]})
+
+print("  stage 0 detail (tid 0): loads landed %d | compute %d | barrier %d ;  stage 2: g %d | H asm %d" % tuple(
+    np.median(x) for x in (c[:,11]-c[:,0], c[:,12]-c[:,11], c[:,1]-c[:,12], c[:,13]-c[:,2], c[:,3]-c[:,13])))
