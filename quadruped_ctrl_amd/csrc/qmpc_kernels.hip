@@ -649,9 +649,19 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
     const double inv_fr = P.inv_fr_norm;
     const double tol = P.tol;
     const int max_iter = P.max_iter;
+    __builtin_amdgcn_s_setprio(3);  // the serial part of the workgroup: win issue arbitration
     auto Hinv = [&](int r, int cidx) __attribute__((always_inline)) {
       const int hi = r > cidx ? r : cidx, lo = r > cidx ? cidx : r;
       return Sb.Hp[hi * (hi + 1) / 2 + lo];
+    };
+    int rbl[RB];  // packed-row base of this lane's variables
+#pragma unroll
+    for (int q = 0; q < RB; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
+    // element (row = lane + 64 q, column j) of H^-1 for a wave-uniform j
+    auto Hcol = [&](int q, int j) __attribute__((always_inline)) {
+      const int row = lane + 64 * q;
+      const int tj = j * (j + 1) / 2;  // scalar
+      return Sb.Hp[(j <= row) ? rbl[q] + j : tj + row];
     };
     // value of the index-major vector v at variable j (per-lane j): a bpermute per 64-block
     auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
@@ -672,6 +682,8 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
 
     unsigned amask = 0;  // stance-slot lane: bit ty = constraint (sl, ty) is in the working set
     int wcid[KW];        // working-slot lane: constraint id in slot w + 64 q, -1 = free
+    int wj1[KW], wj2[KW];   // ... and its row c_w = wa1 e_wj1 + wa2 e_wj2 (cached)
+    double wa1[KW], wa2[KW];
     double lam[KW], rw[KW];
     int khw = 0;         // high-water mark of used working-set slots (uniform)
     int mvalid = 0;      // rows M[0..mvalid) are stored (uniform)
@@ -679,6 +691,8 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
 #pragma unroll
     for (int q = 0; q < KW; ++q) {
       wcid[q] = -1;
+      wj1[q] = wj2[q] = 0;
+      wa1[q] = wa2[q] = 0.0;
       lam[q] = 0.0;
       rw[q] = 0.0;
     }
@@ -688,19 +702,23 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
       //      (normalised by its row norm); none -> optimal
       unsigned key = 0;
       {
+        // slot lane sl needs x[3sl..3sl+2] of the index-major x
         const int j0 = 3 * (lane < nst ? lane : 0);
         const double x0 = gather(xv, j0), x1 = gather(xv, j0 + 1), x2 = gather(xv, j0 + 2);
         if (lane < nst) {
-          const double sv[5] = {(mi * x0 + x2) * inv_fr, (-mi * x0 + x2) * inv_fr, (mi * x1 + x2) * inv_fr,
-                                (-mi * x1 + x2) * inv_fr, fmx - x2};
+          // most violated of this slot's rows outside the working set (normalised)
+          const double fx = mi * x0, fy = mi * x1;
+          double vmin = 0.0;
+          int tmin = -1;
+          const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx - x2};
 #pragma unroll
           for (int ty = 0; ty < 5; ++ty) {
-            if (!((amask >> ty) & 1u) && sv[ty] < -tol) {
-              // more negative -> larger float magnitude -> larger key; low 9 bits = id
-              const unsigned kk = (__float_as_uint((float)(-sv[ty])) & ~0x1FFu) | (unsigned)(5 * lane + ty);
-              key = kk > key ? kk : key;
-            }
+            const bool cand = !((amask >> ty) & 1u) && sv[ty] < vmin;
+            vmin = cand ? sv[ty] : vmin;
+            tmin = cand ? ty : tmin;
           }
+          if (vmin < -tol)  // more negative -> larger float magnitude -> larger key; low 9 bits = id
+            key = (__float_as_uint((float)(-vmin)) & ~0x1FFu) | (unsigned)(5 * lane + tmin);
         }
       }
       const unsigned best = wave_max_u32(key);
@@ -724,18 +742,15 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int row = lane + 64 * q;
-        hc[q] = (row < n) ? pa1 * Hinv(row, pj1) + (two ? pa2 * Hinv(row, pj2) : 0.0) : 0.0;
+        hc[q] = (row < n) ? pa1 * Hcol(q, pj1) + (two ? pa2 * Hcol(q, pj2) : 0.0) : 0.0;
       }
       const double hcn = pa1 * bcast(hc, pj1) + (two ? pa2 * bcast(hc, pj2) : 0.0);  // c_p^T H^-1 c_p
       // d = C_W^T H^-1 c_p does not change while p is being added (only r does)
       double dw[KW];
 #pragma unroll
       for (int q = 0; q < KW; ++q) {
-        int j1 = 0, j2 = 0;
-        double a1 = 0.0, a2 = 0.0;
-        if (wcid[q] >= 0) con_coefs(wcid[q], mi, j1, j2, a1, a2);
-        const double h1 = gather(hc, j1), h2 = gather(hc, j2);
-        dw[q] = a1 * h1 + a2 * h2;
+        const double h1 = gather(hc, wj1[q]), h2 = gather(hc, wj2[q]);
+        dw[q] = (wcid[q] >= 0) ? wa1[q] * h1 + wa2[q] * h2 : 0.0;
       }
       double lp = 0.0;  // multiplier of p
       bool done = false;
@@ -800,7 +815,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
             for (int q = 0; q < RB; ++q) {
               const int row = lane + 64 * q;
               if (row < n) {
-                const double hw = a1 * Hinv(row, j1) + (a2 != 0.0 ? a2 * Hinv(row, j2) : 0.0);
+                const double hw = a1 * Hcol(q, j1) + (a2 != 0.0 ? a2 * Hcol(q, j2) : 0.0);
                 z[q] = __builtin_fma(-rv, hw, z[q]);
               }
             }
@@ -912,6 +927,10 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
           for (int q = 0; q < KW; ++q)
             if (lane + 64 * q == qslot) {
               wcid[q] = p_e;
+              wj1[q] = pj1;
+              wj2[q] = pj2;
+              wa1[q] = pa1;
+              wa2[q] = pa2;
               lam[q] = lp;
               rw[q] = 0.0;
             }
@@ -948,6 +967,8 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
         for (int q = 0; q < KW; ++q)
           if (lane + 64 * q == l) {
             wcid[q] = -1;
+            wj1[q] = wj2[q] = 0;
+            wa1[q] = wa2[q] = 0.0;
             lam[q] = 0.0;
             rw[q] = 0.0;
             dw[q] = 0.0;
@@ -956,6 +977,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
       }
       if (done) break;
     }
+    __builtin_amdgcn_s_setprio(0);
     QMPC_TICK(6);
 
     // ---------------------------------------------------------- outputs
