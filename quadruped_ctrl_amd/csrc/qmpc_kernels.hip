@@ -155,6 +155,10 @@ struct Cfg {
   static constexpr int KW = (KMAX + 63) / 64;  // slots per engine lane
   static constexpr int NS = KMAX * (KMAX + 1) / 2;
   static constexpr int NH = NP * (NP + 1) / 2;
+  // v5 engine: doubles shared by the packed S_W^-1 (front) and the rows of N* (back);
+  // sized so that class 1 keeps 4 workgroups per CU
+  static constexpr int POOL = (RB == 1) ? 2496 : (RB == 2 ? 11400 : NS);
+  static constexpr int NPOOL = POOL > NS ? POOL : NS;
 };
 
 template <int RB>
@@ -165,6 +169,8 @@ struct Smem {
   double fmaxk[64];
   unsigned char sidx[64];
   int nst, status;
+  int mode, u_q, u_kn, u_l;  // v5 engine: block-wide update command
+  double u_s;                // ... and its scalar (1/delta or 1/S_ll)
   // ---- phase-local storage
   union U {
     struct AW {
@@ -190,7 +196,10 @@ struct Smem {
       // pool: (C_W^T H^-1 C_W)^-1 packed the same way, growing from the front with
       // the slot high-water mark; rows M[w] = H^-1 c_w (NP doubles each) from the
       // back while they fit (beyond that they are recomputed from Hp)
-      double Sinv[C::NS];
+      double Sinv[C::NPOOL];
+      // v5 engine: diag(H^-1), the published step z / dual step r of the current update
+      double D[C::NP], zb[C::NP], rb[C::KMAX];
+      double dummy[64];  // sink for predicated-off LDS updates
     } b;
   } u;
 };
@@ -206,8 +215,12 @@ struct Smem {
     if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); \
   } while (0)
 
-template <int RB>
-__device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
+// V5 selects the active-set engine: true = projected-inverse form (all waves
+// update P, N*, S^-1 in parallel; capacity-limited), false = the single-wave
+// Schur form that never overflows.  Returns true when the robot must be re-run
+// with the other engine.
+template <int RB, bool V5>
+__device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW;
   const QmpcParams& P = S.par;  // parked copy: everything after stage 0
@@ -400,7 +413,7 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
       }
     }
     __syncthreads();
-    return;
+    return false;
   }
   const double alpha = (double)P.alpha[(size_t)rid * P.alpha_stride];
 
@@ -632,10 +645,355 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
     }
   }
   for (int k = tid; k < C::NS; k += NT) Sb.Sinv[k] = 0.0;
+  if constexpr (V5) {
+    // diagonal of H^-1: entry (i,i) is register i % CW of column group i / CW
+    if (c == i / CW) {
+      const int r = i % CW;
+      double v = a[0];
+#pragma unroll
+      for (int q = 1; q < CW; ++q) {
+        double t = a[q];
+        asm volatile("" : "+v"(t));
+        v = (r == q) ? t : v;
+      }
+      Sb.D[i] = -v;
+    }
+    if (tid < KMAX) Sb.rb[tid] = 0.0;
+  }
   __syncthreads();
   QMPC_TICK(5);
 
-  // ------------------------------------------------------------ stage 5
+  // ------------------------------------------------------------ stage 5 (V5)
+  // Goldfarb-Idnani in its projected-inverse form.  LDS holds
+  //   P   = H^-1 - H^-1 C_W S^-1 C_W^T H^-1     (packed, starts as H^-1)
+  //   N*  = H^-1 C_W S^-1  (one row of NP doubles per working-set slot, pool back)
+  //   S^-1 (packed, pool front; only needed to drop constraints)
+  // so a step needs no solve at all: z = P c_p (two columns of P), r = N*^T c_p
+  // (two entries per slot).  Wave 0 does that serial part out of registers; the
+  // rank-1 updates of P, N*, S^-1 that follow are spread over ALL waves
+  // (two barriers per step).
+  int iters = 0;
+  bool retry = false;
+  if constexpr (V5) {
+    enum { M_ADD = 1, M_DROP = 2, M_DONE = 3 };
+    const int part = tid / NP;  // 0..3: which quarter of the columns / slots this thread updates
+    const int irow = tid % NP;
+    auto n_row = [&](int w) __attribute__((always_inline)) { return &Sb.Sinv[C::NPOOL - NP * (w + 1)]; };
+    // P += s * u u^T on the packed lower triangle, spread evenly over the block:
+    // thread (r2, p8) takes rows r2 and NP-1-r2 (their lengths add up to NP+1) and
+    // every 8th column; fixed trip counts, so the LDS traffic of a row is in flight together
+    const int r2 = tid % (NP / 2), p8 = tid / (NP / 2);
+    auto rank1 = [&](const double* u, double sc) __attribute__((always_inline)) {
+      // branch-free: entries outside the triangle are redirected to a dummy word, so
+      // all loads of the thread are issued together (no per-element exec masking)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = half ? NP - 1 - r2 : r2;
+        const bool rok = row < n;
+        const double ui = u[rok ? row : 0] * sc;
+        double* prow = &Sb.Hp[row * (row + 1) / 2];
+        double* pa[NP / 8];
+        double pv[NP / 8], uv[NP / 8];
+#pragma unroll
+        for (int m = 0; m < NP / 8; ++m) {
+          const int j = p8 + 8 * m;
+          const bool ok = rok && j <= row;
+          pa[m] = ok ? &prow[j] : &Sb.dummy[tid & 63];
+          pv[m] = *pa[m];
+          uv[m] = u[ok ? j : 0];
+        }
+#pragma unroll
+        for (int m = 0; m < NP / 8; ++m) *pa[m] = __builtin_fma(ui, uv[m], pv[m]);
+      }
+    };
+    // engine registers
+    const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
+    const int max_iter = P.max_iter;
+    unsigned amask = 0;
+    int wcid[KW];
+    double lam[KW];
+    int khw = 0, status = 0;
+    bool need_p = true;
+    int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
+    double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
+    int rbl[RB];
+#pragma unroll
+    for (int q = 0; q < KW; ++q) {
+      wcid[q] = -1;
+      lam[q] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
+    auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+      double out = 0.0;
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const double cand = __shfl(v[q], j & 63);
+        if ((j >> 6) == q) out = cand;
+      }
+      return out;
+    };
+    auto bcast = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+      return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
+    };
+    auto Pcol = [&](int q, int j) __attribute__((always_inline)) {
+      const int row = lane + 64 * q;
+      const int tj = j * (j + 1) / 2;
+      return Sb.Hp[(j <= row) ? rbl[q] + j : tj + row];
+    };
+    if (engine) __builtin_amdgcn_s_setprio(3);
+
+    while (true) {
+      if (engine) {
+        int mode = 0;
+        if (need_p) {
+          // ---- most violated constraint outside the working set (normalised), or done
+          unsigned key = 0;
+          const int j0 = 3 * (lane < nst ? lane : 0);
+          const double x0 = gather(xv, j0), x1 = gather(xv, j0 + 1), x2 = gather(xv, j0 + 2);
+          if (lane < nst) {
+            const double fx = mi * x0, fy = mi * x1;
+            double vmin = 0.0;
+            int tmin = -1;
+            const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx - x2};
+#pragma unroll
+            for (int ty = 0; ty < 5; ++ty) {
+              const bool cand = !((amask >> ty) & 1u) && sv[ty] < vmin;
+              vmin = cand ? sv[ty] : vmin;
+              tmin = cand ? ty : tmin;
+            }
+            if (vmin < -tol) key = (__float_as_uint((float)(-vmin)) & ~0x1FFu) | (unsigned)(5 * lane + tmin);
+          }
+          const unsigned best = wave_max_u32(key);
+          if (best == 0u) {
+            mode = M_DONE;
+          } else if (iters >= max_iter) {
+            status |= QMPC_DEV_ST_MAXITER;
+            mode = M_DONE;
+          } else {
+            p_e = (int)(best & 0x1FFu);
+            psl = p_e / 5;
+            pty = p_e - 5 * psl;
+            con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+            p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
+            lp = 0.0;
+            need_p = false;
+          }
+        }
+        if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
+        if (mode != M_DONE) {
+          const bool two = (pa2 != 0.0);
+          // z = P c_p (index-major), r = N*^T c_p (slot lanes)
+          double z[RB];
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            const int row = lane + 64 * q;
+            z[q] = (row < n) ? pa1 * Pcol(q, pj1) + (two ? pa2 * Pcol(q, pj2) : 0.0) : 0.0;
+          }
+          double rw[KW];
+#pragma unroll
+          for (int q = 0; q < KW; ++q) {
+            const int w = lane + 64 * q;
+            rw[q] = 0.0;
+            if (wcid[q] >= 0) rw[q] = pa1 * n_row(w)[pj1] + (two ? pa2 * n_row(w)[pj2] : 0.0);
+          }
+          const double delta = pa1 * bcast(z, pj1) + (two ? pa2 * bcast(z, pj2) : 0.0);
+          const double cn = pa1 * pa1 * Sb.D[pj1] + (two ? pa2 * pa2 * Sb.D[pj2] : 0.0);  // scale of c_p^T H^-1 c_p
+          const double sp = pa1 * bcast(xv, pj1) + (two ? pa2 * bcast(xv, pj2) : 0.0) - p_rhs;
+          if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
+          const bool dep = !(delta > 1e-11 * cn);
+          const double rdelta = fast_rcp(dep ? 1.0 : delta);
+          const double t2 = dep ? __builtin_inf() : -sp * rdelta;
+          double ratio = __builtin_inf();
+          int lq = 0;
+#pragma unroll
+          for (int q = 0; q < KW; ++q) {
+            if (wcid[q] >= 0 && rw[q] > 0.0) {
+              double qv = lam[q] * fast_rcp(rw[q]);
+              qv = qv > 0.0 ? qv : 0.0;
+              if (qv < ratio) {
+                ratio = qv;
+                lq = q;
+              }
+            }
+          }
+          double t1 = __builtin_inf();
+          int l = -1;
+          if (khw > 0) {
+            t1 = wave_min_pos_f64(ratio);
+            if (t1 < __builtin_inf()) {
+              const unsigned long long m = __ballot(ratio == t1);
+              const int ll = __ffsll((long long)m) - 1;
+              l = ll + 64 * __builtin_amdgcn_readlane(lq, ll);
+            }
+          }
+          const double t = (t2 <= t1) ? t2 : t1;
+          if (!(t < __builtin_inf())) {
+            status |= QMPC_DEV_ST_INFEASIBLE;
+            mode = M_DONE;
+          } else {
+            if (!dep) {
+#pragma unroll
+              for (int q = 0; q < RB; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
+            lp += t;
+            iters += 1;
+            if (t2 <= t1) {
+              // full step: p joins the working set in the first free slot
+              int qslot = -1;
+#pragma unroll
+              for (int q = 0; q < KW; ++q) {
+                const bool fr = (lane + 64 * q < KMAX) && (wcid[q] < 0);
+                const unsigned long long m = __ballot(fr);
+                if (qslot < 0 && m) qslot = 64 * q + __ffsll((long long)m) - 1;
+              }
+              const int kn = (qslot >= 0 && qslot + 1 > khw) ? qslot + 1 : khw;
+              if (qslot < 0 || kn * (kn + 1) / 2 + NP * kn > C::NPOOL) {
+                retry = true;  // out of room: the robot is re-run with the Schur-form engine
+                mode = M_DONE;
+              } else {
+#pragma unroll
+                for (int q = 0; q < RB; ++q) Sb.zb[lane + 64 * q] = z[q];
+#pragma unroll
+                for (int q = 0; q < KW; ++q)
+                  if (lane + 64 * q < KMAX) Sb.rb[lane + 64 * q] = rw[q];
+#pragma unroll
+                for (int q = 0; q < KW; ++q)
+                  if (lane + 64 * q == qslot) {
+                    wcid[q] = p_e;
+                    lam[q] = lp;
+                  }
+                if (lane == psl) amask |= (1u << pty);
+                if (lane == 0) {
+                  S.u_q = qslot;
+                  S.u_kn = kn;
+                  S.u_s = rdelta;
+                }
+                khw = kn;
+                need_p = true;
+                mode = M_ADD;
+              }
+            } else {
+              // partial step: the multiplier of slot l reached zero -> drop it
+              const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, (l >> 6) < KW ? (l >> 6) : 0), l & 63);
+#pragma unroll
+              for (int q = 0; q < KW; ++q)
+                if (lane + 64 * q == l) {
+                  wcid[q] = -1;
+                  lam[q] = 0.0;
+                }
+              if (lane == de / 5) amask &= ~(1u << (de % 5));
+              if (lane == 0) {
+                S.u_l = l;
+                S.u_kn = khw;
+                S.u_s = fast_rcp(Sb.Sinv[sym_idx(l, l)]);
+              }
+              mode = M_DROP;
+            }
+          }
+        }
+        if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
+        if (lane == 0) S.mode = mode;
+      }
+      __syncthreads();  // ---- A: the command is published
+      if (dbg_clk && tid == 0 && iters == 1) dbg_clk[11] = clock64();
+      const int mode = S.mode;
+      if (mode == M_DONE) break;
+      if (mode == M_ADD) {
+        const int qs = S.u_q, kn = S.u_kn;
+        const double dinv = S.u_s;
+        rank1(Sb.zb, -dinv);  // P -= z z^T / delta
+        if (irow < n) {
+          const double zi = Sb.zb[irow] * dinv;
+          // N*_w -= z r_w / delta ; N*_q = z / delta
+          for (int w0 = part; w0 < kn; w0 += 8) {
+            const int w1 = w0 + 4;
+            double* nr0 = n_row(w0);
+            double* nr1 = n_row(w1 < kn ? w1 : w0);
+            const double o0 = nr0[irow], o1 = nr1[irow], r0v = Sb.rb[w0], r1v = Sb.rb[w1 < kn ? w1 : w0];
+            nr0[irow] = (w0 == qs) ? zi : __builtin_fma(-zi, r0v, o0);
+            if (w1 < kn) nr1[irow] = (w1 == qs) ? zi : __builtin_fma(-zi, r1v, o1);
+          }
+        }
+        // S^-1 bordered update: S[a][b] += r_a r_b/delta ; S[q][a] = -r_a/delta ; S[q][q] = 1/delta
+        if (irow < kn) {
+          const int lo = irow;
+          const double rlo = Sb.rb[lo];
+          for (int hi = lo + part; hi < kn; hi += 4) {
+            const int idx = hi * (hi + 1) / 2 + lo;
+            const double rhi = Sb.rb[hi];
+            double v;
+            if (hi == qs && lo == qs) v = dinv;
+            else if (hi == qs) v = -rlo * dinv;
+            else if (lo == qs) v = -rhi * dinv;
+            else v = __builtin_fma(rhi * dinv, rlo, Sb.Sinv[idx]);
+            Sb.Sinv[idx] = v;
+          }
+        }
+        if (dbg_clk && tid == 0 && iters == 1) dbg_clk[12] = clock64();
+        __syncthreads();  // ---- B
+        if (dbg_clk && tid == 0 && iters == 1) dbg_clk[13] = clock64();
+        if (tid == 0) Sb.rb[qs] = 0.0;  // a fresh slot has r = 0 until it is computed again
+      } else {  // M_DROP
+        const int l = S.u_l, kn = S.u_kn;
+        const double ginv = S.u_s;  // 1 / S^-1[l][l]
+        const double* ul = n_row(l);
+        rank1(ul, ginv);  // P += u u^T / S^-1[l][l]
+        __syncthreads();  // u (row l of N*) is read by everybody above, rewritten below
+        if (irow < n) {
+          const double ui = ul[irow] * ginv;
+          // N*_w -= u S^-1[w][l] / S^-1[l][l]   (w != l)
+          for (int w = part; w < kn; w += 4)
+            if (w != l) {
+              double* nr = n_row(w);
+              nr[irow] = __builtin_fma(-ui, Sb.Sinv[sym_idx(w, l)], nr[irow]);
+            }
+        }
+        // S' = S - S[:,l] S[l,:] / S[l][l] on the other slots
+        if (irow < kn && irow != l) {
+          const int lo = irow;
+          const double slo = Sb.Sinv[sym_idx(l, lo)] * ginv;
+          for (int hi = lo + part; hi < kn; hi += 4)
+            if (hi != l) {
+              const int idx = hi * (hi + 1) / 2 + lo;
+              Sb.Sinv[idx] = __builtin_fma(-slo, Sb.Sinv[sym_idx(hi, l)], Sb.Sinv[idx]);
+            }
+        }
+        __syncthreads();  // ---- B
+        if (tid < kn) Sb.Sinv[sym_idx(tid, l)] = 0.0;
+        if (tid == 0) Sb.rb[l] = 0.0;
+        if (irow < n && part == 0) n_row(l)[irow] = 0.0;
+        __syncthreads();
+      }
+    }
+    if (engine) {
+      __builtin_amdgcn_s_setprio(0);
+      QMPC_TICK(6);
+      if (!retry) {
+        // outputs: get_solution(0..11) = forces of the four feet at horizon step 0
+        // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685)
+        if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const int j = lane + 64 * q;
+          if (j < n) {
+            const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
+            if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xv[q];
+            if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
+          }
+        }
+        if (lane == 0) {
+          P.status[rid] = S.status | status;
+          if (P.iters) P.iters[rid] = iters;
+        }
+      }
+      if (lane == 0) S.mode = retry ? 1 : 0;
+    }
+  } else {
+  // ------------------------------------------------------------ stage 5 (Schur form)
   // Goldfarb-Idnani dual active set on the explicit inverse, run by wave 0
   // alone: no block barrier inside the loop.  Engine state lives in registers:
   //   lane = variable index i (+64q)   : x_i, (H^-1 c_p)_i, z_i
@@ -643,7 +1001,6 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
   //   lane = working-set slot w (+64q) : constraint id, multiplier, r_w
   // Cross-lane traffic is DPP / readlane / bpermute; matrix data comes from the
   // packed H^-1, S_W^-1 and the pooled rows H^-1 c_w in LDS.
-  int iters = 0;
   if (engine) {
     const double mi = P.mu_inv;
     const double inv_fr = P.inv_fr_norm;
@@ -1000,8 +1357,11 @@ __device__ void solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
       if (P.iters) P.iters[rid] = iters;
     }
   }
+    if (engine && lane == 0) S.mode = 0;
+  }
   __syncthreads();  // the other waves wait here for the engine
   QMPC_TICK(7);
+  return S.mode != 0;
 }
 
 }  // namespace
@@ -1024,7 +1384,16 @@ __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void q
     rid = P.list[blockIdx.x];
   }
   if (threadIdx.x == 0) S.par = P;  // visible to all after the first barrier inside solve_one
-  solve_one<RB>(rid, S, P);
+  if constexpr (RB < 3) {
+    // projected-inverse engine first; the (rare) robot that runs out of pool is
+    // solved again from scratch with the Schur-form engine, which cannot overflow
+    if (solve_one<RB, true>(rid, S, P)) {
+      __syncthreads();
+      solve_one<RB, false>(rid, S, P);
+    }
+  } else {
+    solve_one<RB, false>(rid, S, P);
+  }
 }
 
 extern "C" size_t qmpc_smem_bytes(int rb) {

@@ -44,3 +44,8 @@ print("  iters percentiles", {q: int(np.percentile(it, q)) for q in qs}, " AS cy
 
 print("  stage 0 detail (tid 0): loads landed %d | compute %d | barrier %d ;  stage 2: g %d | H asm %d" % tuple(
     np.median(x) for x in (c[:,11]-c[:,0], c[:,12]-c[:,11], c[:,1]-c[:,12], c[:,13]-c[:,2], c[:,3]-c[:,13])))
+
+ok = (it > 0) & (c[:, 13] > 0) & (c[:, 8] > 0)
+if ok.any():
+    print("  v5 first iteration (tid 0, median): select %d | z,r,delta %d | step+publish %d | barrier A %d | parallel update %d | barrier B %d" % tuple(
+        np.median(x[ok]) for x in (c[:,8]-c[:,5], c[:,9]-c[:,8], c[:,10]-c[:,9], c[:,11]-c[:,10], c[:,12]-c[:,11], c[:,13]-c[:,12])))
