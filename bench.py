@@ -147,7 +147,7 @@ def main():
     status = o["status"].cpu().numpy()
     iters = o["iters"].cpu().numpy()
     nst = (b["gait"] != 0).sum(1)
-    n_fail = int((status != 0).sum())
+    n_fail = int(((status & 15) != 0).sum())
 
     if rank == 0:
         total_qp = per_gpu * world * args.steps

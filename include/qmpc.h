@@ -51,6 +51,10 @@ extern "C" {
 #define QMPC_ST_INFEASIBLE 4 /* constraints inconsistent (cannot happen for
                                 friction pyramids with f_max >= 0) */
 #define QMPC_ST_WS_FULL 8    /* working-set capacity exceeded */
+#define QMPC_ST_FALLBACK 16  /* informational, NOT an error: the robot was solved by the
+                                slower Schur-form engine because the fast engine's
+                                working-set pool was exhausted */
+#define QMPC_ST_ERROR_MASK 15
 
 typedef struct qmpc_ctx* qmpc_handle;
 

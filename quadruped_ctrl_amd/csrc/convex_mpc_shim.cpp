@@ -56,7 +56,7 @@ void solve_floats(const float* p, const float* v, const float* q, const float* w
   }
   g.status = st;
   g.iters = it;
-  if (st != 0) std::printf("failed to solve! (status bits %d)\n", st);  // SolverMPC.cpp:541
+  if (st & QMPC_ST_ERROR_MASK) std::printf("failed to solve! (status bits %d)\n", st);  // SolverMPC.cpp:541
   g.has_solved = true;
 }
 

@@ -1390,6 +1390,8 @@ __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void q
     if (solve_one<RB, true>(rid, S, P)) {
       __syncthreads();
       solve_one<RB, false>(rid, S, P);
+      __syncthreads();
+      if (threadIdx.x == 0) P.status[rid] |= QMPC_DEV_ST_FALLBACK;  // informational
     }
   } else {
     solve_one<RB, false>(rid, S, P);

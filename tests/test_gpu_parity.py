@@ -51,7 +51,7 @@ def test_golden_vectors(path, mpc_factory):
     """Committed reference outputs (generated with the reference's qpOASES)."""
     b = load_gold(path)
     res = mpc_factory(b).solve(b, full=True)
-    assert (res["status"] == 0).all()
+    assert ((res["status"] & 15) == 0).all()
     ref = b["q_soln"]
     assert rel_f0(res["grf"], ref).max() < tol_for(b["horizon"])
     full = np.abs(res["soln"] - ref).max(1) / np.maximum(np.abs(ref).max(1), 1.0)
@@ -67,7 +67,7 @@ def test_golden_vectors(path, mpc_factory):
 def test_configs_vs_live_oracle(cfg, B, mpc_factory):
     b = W.make_config(cfg, batch=B)
     res = mpc_factory(b).solve(b, full=True)
-    assert (res["status"] == 0).all()
+    assert ((res["status"] & 15) == 0).all()
     ref, nwsr, rc = O.solve_batch(b)
     assert (rc == 0).all()
     assert rel_f0(res["grf"], ref).max() < tol_for(b["horizon"])
@@ -112,7 +112,7 @@ def test_edge_cases(mpc_factory):
     b["gait"][2] = 0
     b["gait"][2, 4 * 9 + 3] = 1            # one foot, LAST step only -> step-0 forces zero
     res = mpc_factory(b).solve(b, full=True)
-    assert (res["status"] == 0).all()
+    assert ((res["status"] & 15) == 0).all()
     ref, nwsr, rc = O.solve_batch(b)
     assert rel_f0(res["grf"], ref).max() < 1e-4
     assert np.all(res["grf"][0] == 0) and np.all(res["soln"][0] == 0) and res["iters"][0] == 0
@@ -128,7 +128,7 @@ def test_force_limit_active(mpc_factory):
     b = W.make_config(1, batch=32)
     b["f_max"] = 30.0
     res = mpc_factory(b).solve(b, full=True)
-    assert (res["status"] == 0).all()
+    assert ((res["status"] & 15) == 0).all()
     ref, nwsr, rc = O.solve_batch(b)
     assert (rc == 0).all()
     assert rel_f0(res["grf"], ref).max() < 1e-4
@@ -143,7 +143,7 @@ def test_x_drag_and_per_robot_parameters(mpc_factory):
     b["alpha"] = (4e-5 * rng.uniform(0.25, 2.0, 48)).astype(np.float32)
     b["weights"] = (b["weights"] * rng.uniform(0.5, 2.0, (48, 12))).astype(np.float32)
     res = mpc_factory(b).solve(b, full=True)
-    assert (res["status"] == 0).all()
+    assert ((res["status"] & 15) == 0).all()
     ref, nwsr, rc = O.solve_batch(b)
     assert rel_f0(res["grf"], ref).max() < 1e-4
 
@@ -178,7 +178,7 @@ def test_full_size_kkt_properties(mpc_factory):
         Hd, gd, ld = m.debug_dump(B)
         res = m.solve(b, full=True)
         m.debug_off()
-        assert (res["status"] == 0).all()
+        assert ((res["status"] & 15) == 0).all()
         h = b["horizon"]
         mi = float(np.float32(1) / np.float32(b["mu"]))
         f = res["soln"].reshape(B, 4 * h, 3)
@@ -273,3 +273,40 @@ def test_size_hint(mpc_factory):
     assert np.array_equal(again["grf"], base["grf"])
     for _ in range(3):                               # repeated calls reuse the ping-ponged counters
         assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+
+
+def test_many_active_constraints_engine_fallback(mpc_factory):
+    """Tight force limit + hard lateral demand: most stance foot-steps sit on the
+    f_max row AND a friction row, so the working set outgrows the fast engine's
+    pool; those robots are re-solved by the Schur-form engine (status bit 16,
+    informational).  The reference caps qpOASES at nWSR = 100 (SolverMPC.cpp:435)
+    and silently returns a non-optimal point beyond that, so the checker here is
+    the same qpOASES build with the cap lifted, on the GPU's own assembled QP
+    (solver parity)."""
+    b = W.make_config(1, batch=12)
+    b["f_max"] = 22.0
+    b["traj"].reshape(12, 10, 12)[:, :, 10] = 3.0      # demand a large lateral velocity
+    b["traj"].reshape(12, 10, 12)[:, :, 4] += 0.5
+    b["weights"][:, 10] = 50.0
+    b["weights"][:, 4] = 200.0
+    m = mpc_factory(b)
+    Hd, gd, ld = m.debug_dump(12)
+    res = m.solve(b, full=True)
+    m.debug_off()
+    Hd, gd = Hd.cpu().numpy(), gd.cpu().numpy()
+    assert ((res["status"] & 15) == 0).all()
+    worst, over_cap = 0.0, 0
+    for i in range(12):
+        H, g, A, lb, ub, x0 = O.assemble(b, i)
+        ve, Hr, gr, Ar, lr, ur = O.reduce(H, g, A, lb, ub)
+        n = gr.size
+        xq, y, used, rc, irc = O.qpoases(Hd[i][:n, :n], gd[i][:n], Ar, lr, ur, nwsr=5000)
+        assert rc == 0 and irc == 0
+        over_cap += used > 100
+        xs = res["soln"][i][~ve]
+        worst = max(worst, np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0))
+    print("iters max", res["iters"].max(), "fallback robots", int((res["status"] & 16).astype(bool).sum()),
+          "reference over its nWSR cap on", over_cap, "worst err", worst)
+    assert worst < 1e-7
+    assert res["iters"].max() > 30            # a genuinely large working set
+    assert (res["status"] & 16).any()         # ... that exercised the fallback engine
