@@ -159,6 +159,7 @@ struct Cfg {
   // sized so that class 1 keeps 4 workgroups per CU
   static constexpr int POOL = (RB == 1) ? 2496 : (RB == 2 ? 11400 : NS);
   static constexpr int NPOOL = POOL > NS ? POOL : NS;
+  static constexpr int KS = (RB == 1) ? 32 : 64;  // event-form engine: working-set slot capacity (one per lane)
 };
 
 template <int RB>
@@ -644,7 +645,7 @@ __device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
       if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  for (int k = tid; k < C::NS; k += NT) Sb.Sinv[k] = 0.0;
+  for (int k = tid; k < (V5 ? C::NPOOL : C::NS); k += NT) Sb.Sinv[k] = 0.0;  // V5: event rows start out zero
   if constexpr (V5) {
     // diagonal of H^-1: entry (i,i) is register i % CW of column group i / CW
     if (c == i / CW) {
@@ -658,94 +659,74 @@ __device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
       }
       Sb.D[i] = -v;
     }
-    if (tid < KMAX) Sb.rb[tid] = 0.0;
   }
   __syncthreads();
   QMPC_TICK(5);
 
-  // ------------------------------------------------------------ stage 5 (V5)
-  // Goldfarb-Idnani in its projected-inverse form.  LDS holds
-  //   P   = H^-1 - H^-1 C_W S^-1 C_W^T H^-1     (packed, starts as H^-1)
-  //   N*  = H^-1 C_W S^-1  (one row of NP doubles per working-set slot, pool back)
-  //   S^-1 (packed, pool front; only needed to drop constraints)
-  // so a step needs no solve at all: z = P c_p (two columns of P), r = N*^T c_p
-  // (two entries per slot).  Wave 0 does that serial part out of registers; the
-  // rank-1 updates of P, N*, S^-1 that follow are spread over ALL waves
-  // (two barriers per step).
+  // ------------------------------------------------------------ stage 5 (event form)
+  // Goldfarb-Idnani with the projected inverse kept as a SUM OF EVENTS.  Every
+  // change of the working set W is a rank-1 event (z~, g~):
+  //   add  p -> slot q : z~ = P c_p / sqrt(delta),  g~_w = -r_w / sqrt(delta), g~_q = 1 / sqrt(delta)
+  //   drop slot l      : z~ = N*_l / sqrt(gamma),    g~_w = -S^-1[w][l] / sqrt(gamma)   (gamma = S^-1[l][l])
+  // and the three matrices of the method are
+  //   P    = H^-1 - sum_add z~ z~^T + sum_drop z~ z~^T     (projected inverse, n x n)
+  //   N*   = sum_all z~ g~^T                              (H^-1 C_W S^-1, n x slots)
+  //   S^-1 = sum_add g~ g~^T - sum_drop g~ g~^T           ((C_W^T H^-1 C_W)^-1)
+  // (column l of every g~ is zeroed when slot l is dropped).  Nothing is ever
+  // updated in place: a step costs two columns of the packed H^-1 plus, per event,
+  // two broadcast loads and two FMAs per lane -- no block barrier, no rank-1
+  // sweep over n^2 entries, and the other waves of the block are not needed.
+  // Events live in the LDS pool: add events from the front, drop events from the
+  // back (so neither loop needs a sign), rows in between stay zero.
   int iters = 0;
   bool retry = false;
   if constexpr (V5) {
-    enum { M_ADD = 1, M_DROP = 2, M_DONE = 3 };
-    const int part = tid / NP;  // 0..3: which quarter of the columns / slots this thread updates
-    const int irow = tid % NP;
-    auto n_row = [&](int w) __attribute__((always_inline)) { return &Sb.Sinv[C::NPOOL - NP * (w + 1)]; };
-    // P += s * u u^T on the packed lower triangle, spread evenly over the block:
-    // thread (r2, p8) takes rows r2 and NP-1-r2 (their lengths add up to NP+1) and
-    // every 8th column; fixed trip counts, so the LDS traffic of a row is in flight together
-    const int r2 = tid % (NP / 2), p8 = tid / (NP / 2);
-    auto rank1 = [&](const double* u, double sc) __attribute__((always_inline)) {
-      // branch-free: entries outside the triangle are redirected to a dummy word, so
-      // all loads of the thread are issued together (no per-element exec masking)
+    if (engine) {
+      constexpr int KS = C::KS, EV = NP + KS, KEV = (C::NPOOL / EV) & ~3;
+      double* const pool = Sb.Sinv;
+      const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
+      const int max_iter = P.max_iter;
+      unsigned amask = 0;  // stance-slot lane: bit ty = constraint (slot, ty) is in the working set
+      int wcid = -1;       // working-slot lane: constraint id in slot `lane`, -1 = free
+      double lam = 0.0;    // ... and its multiplier
+      int khw = 0, status = 0, neva = 0, nevd = 0;
+      bool need_p = true;
+      int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
+      double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
+      int rbl[RB];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int row = half ? NP - 1 - r2 : r2;
-        const bool rok = row < n;
-        const double ui = u[rok ? row : 0] * sc;
-        double* prow = &Sb.Hp[row * (row + 1) / 2];
-        double* pa[NP / 8];
-        double pv[NP / 8], uv[NP / 8];
+      for (int q = 0; q < RB; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
+      const int gl_off = NP + (lane & (KS - 1));  // this lane's entry of an event's g~
+      auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+        double out = 0.0;
 #pragma unroll
-        for (int m = 0; m < NP / 8; ++m) {
-          const int j = p8 + 8 * m;
-          const bool ok = rok && j <= row;
-          pa[m] = ok ? &prow[j] : &Sb.dummy[tid & 63];
-          pv[m] = *pa[m];
-          uv[m] = u[ok ? j : 0];
+        for (int q = 0; q < RB; ++q) {
+          const double cand = __shfl(v[q], j & 63);
+          if ((j >> 6) == q) out = cand;
         }
-#pragma unroll
-        for (int m = 0; m < NP / 8; ++m) *pa[m] = __builtin_fma(ui, uv[m], pv[m]);
-      }
-    };
-    // engine registers
-    const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
-    const int max_iter = P.max_iter;
-    unsigned amask = 0;
-    int wcid[KW];
-    double lam[KW];
-    int khw = 0, status = 0;
-    bool need_p = true;
-    int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
-    double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
-    int rbl[RB];
-#pragma unroll
-    for (int q = 0; q < KW; ++q) {
-      wcid[q] = -1;
-      lam[q] = 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < RB; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
-    auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
-      double out = 0.0;
-#pragma unroll
-      for (int q = 0; q < RB; ++q) {
-        const double cand = __shfl(v[q], j & 63);
-        if ((j >> 6) == q) out = cand;
-      }
-      return out;
-    };
-    auto bcast = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
-      return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
-    };
-    auto Pcol = [&](int q, int j) __attribute__((always_inline)) {
-      const int row = lane + 64 * q;
-      const int tj = j * (j + 1) / 2;
-      return Sb.Hp[(j <= row) ? rbl[q] + j : tj + row];
-    };
-    if (engine) __builtin_amdgcn_s_setprio(3);
+        return out;
+      };
+      auto bcast = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+        return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
+      };
+      // element (row = lane + 64 q, column j) of H^-1 for a wave-uniform j
+      auto Hcol = [&](int q, int j) __attribute__((always_inline)) {
+        const int row = lane + 64 * q;
+        const int tj = j * (j + 1) / 2;
+        return Sb.Hp[(j <= row) ? rbl[q] + j : tj + row];
+      };
+      // 1/sqrt(d), d > 0, to full double precision: v_rsq_f64 seed + two Newton steps
+      auto rsqrt_full = [&](double d) __attribute__((always_inline)) {
+        double y = __builtin_amdgcn_rsq(d);
+        double e = __builtin_fma(-d * y, y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+        e = __builtin_fma(-d * y, y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+        return y;
+      };
+      __builtin_amdgcn_s_setprio(3);  // the serial part of the workgroup: win issue arbitration
 
-    while (true) {
-      if (engine) {
-        int mode = 0;
+      while (true) {
         if (need_p) {
           // ---- most violated constraint outside the working set (normalised), or done
           unsigned key = 0;
@@ -765,210 +746,162 @@ __device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
             if (vmin < -tol) key = (__float_as_uint((float)(-vmin)) & ~0x1FFu) | (unsigned)(5 * lane + tmin);
           }
           const unsigned best = wave_max_u32(key);
-          if (best == 0u) {
-            mode = M_DONE;
-          } else if (iters >= max_iter) {
+          if (best == 0u) break;
+          if (iters >= max_iter) {
             status |= QMPC_DEV_ST_MAXITER;
-            mode = M_DONE;
-          } else {
-            p_e = (int)(best & 0x1FFu);
-            psl = p_e / 5;
-            pty = p_e - 5 * psl;
-            con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
-            p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
-            lp = 0.0;
-            need_p = false;
+            break;
           }
+          p_e = (int)(best & 0x1FFu);
+          psl = p_e / 5;
+          pty = p_e - 5 * psl;
+          con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+          p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
+          lp = 0.0;
+          need_p = false;
         }
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
-        if (mode != M_DONE) {
-          const bool two = (pa2 != 0.0);
-          // z = P c_p (index-major), r = N*^T c_p (slot lanes)
-          double z[RB];
+        // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
+        double z[RB];
 #pragma unroll
-          for (int q = 0; q < RB; ++q) {
-            const int row = lane + 64 * q;
-            z[q] = (row < n) ? pa1 * Pcol(q, pj1) + (two ? pa2 * Pcol(q, pj2) : 0.0) : 0.0;
-          }
-          double rw[KW];
-#pragma unroll
-          for (int q = 0; q < KW; ++q) {
-            const int w = lane + 64 * q;
-            rw[q] = 0.0;
-            if (wcid[q] >= 0) rw[q] = pa1 * n_row(w)[pj1] + (two ? pa2 * n_row(w)[pj2] : 0.0);
-          }
-          const double delta = pa1 * bcast(z, pj1) + (two ? pa2 * bcast(z, pj2) : 0.0);
-          const double cn = pa1 * pa1 * Sb.D[pj1] + (two ? pa2 * pa2 * Sb.D[pj2] : 0.0);  // scale of c_p^T H^-1 c_p
-          const double sp = pa1 * bcast(xv, pj1) + (two ? pa2 * bcast(xv, pj2) : 0.0) - p_rhs;
-          if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
-          const bool dep = !(delta > 1e-11 * cn);
-          const double rdelta = fast_rcp(dep ? 1.0 : delta);
-          const double t2 = dep ? __builtin_inf() : -sp * rdelta;
-          double ratio = __builtin_inf();
-          int lq = 0;
-#pragma unroll
-          for (int q = 0; q < KW; ++q) {
-            if (wcid[q] >= 0 && rw[q] > 0.0) {
-              double qv = lam[q] * fast_rcp(rw[q]);
-              qv = qv > 0.0 ? qv : 0.0;
-              if (qv < ratio) {
-                ratio = qv;
-                lq = q;
-              }
-            }
-          }
-          double t1 = __builtin_inf();
-          int l = -1;
-          if (khw > 0) {
-            t1 = wave_min_pos_f64(ratio);
-            if (t1 < __builtin_inf()) {
-              const unsigned long long m = __ballot(ratio == t1);
-              const int ll = __ffsll((long long)m) - 1;
-              l = ll + 64 * __builtin_amdgcn_readlane(lq, ll);
-            }
-          }
-          const double t = (t2 <= t1) ? t2 : t1;
-          if (!(t < __builtin_inf())) {
-            status |= QMPC_DEV_ST_INFEASIBLE;
-            mode = M_DONE;
-          } else {
-            if (!dep) {
-#pragma unroll
-              for (int q = 0; q < RB; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
-            lp += t;
-            iters += 1;
-            if (t2 <= t1) {
-              // full step: p joins the working set in the first free slot
-              int qslot = -1;
-#pragma unroll
-              for (int q = 0; q < KW; ++q) {
-                const bool fr = (lane + 64 * q < KMAX) && (wcid[q] < 0);
-                const unsigned long long m = __ballot(fr);
-                if (qslot < 0 && m) qslot = 64 * q + __ffsll((long long)m) - 1;
-              }
-              const int kn = (qslot >= 0 && qslot + 1 > khw) ? qslot + 1 : khw;
-              if (qslot < 0 || kn * (kn + 1) / 2 + NP * kn > C::NPOOL) {
-                retry = true;  // out of room: the robot is re-run with the Schur-form engine
-                mode = M_DONE;
-              } else {
-#pragma unroll
-                for (int q = 0; q < RB; ++q) Sb.zb[lane + 64 * q] = z[q];
-#pragma unroll
-                for (int q = 0; q < KW; ++q)
-                  if (lane + 64 * q < KMAX) Sb.rb[lane + 64 * q] = rw[q];
-#pragma unroll
-                for (int q = 0; q < KW; ++q)
-                  if (lane + 64 * q == qslot) {
-                    wcid[q] = p_e;
-                    lam[q] = lp;
-                  }
-                if (lane == psl) amask |= (1u << pty);
-                if (lane == 0) {
-                  S.u_q = qslot;
-                  S.u_kn = kn;
-                  S.u_s = rdelta;
-                }
-                khw = kn;
-                need_p = true;
-                mode = M_ADD;
-              }
-            } else {
-              // partial step: the multiplier of slot l reached zero -> drop it
-              const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, (l >> 6) < KW ? (l >> 6) : 0), l & 63);
-#pragma unroll
-              for (int q = 0; q < KW; ++q)
-                if (lane + 64 * q == l) {
-                  wcid[q] = -1;
-                  lam[q] = 0.0;
-                }
-              if (lane == de / 5) amask &= ~(1u << (de % 5));
-              if (lane == 0) {
-                S.u_l = l;
-                S.u_kn = khw;
-                S.u_s = fast_rcp(Sb.Sinv[sym_idx(l, l)]);
-              }
-              mode = M_DROP;
-            }
-          }
+        for (int q = 0; q < RB; ++q) {
+          const int row = lane + 64 * q;
+          z[q] = (row < n) ? __builtin_fma(pa2, Hcol(q, pj2), pa1 * Hcol(q, pj1)) : 0.0;
         }
+        double rw = 0.0;
+        // four events per trip (rows past the last event are zero): y = z~^T c_p,
+        // z -= +-y z~ , r += y g~
+        auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
+          constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
+          for (int t0 = 0; t0 < cnt; t0 += 4) {
+            const double* ev = pool + (base + DIR * t0) * EV;
+            double ya[4], yb[4], zl[4][RB], gl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double* eu = ev + DIR * u * EV;
+              ya[u] = eu[pj1];
+              yb[u] = eu[pj2];
+#pragma unroll
+              for (int q = 0; q < RB; ++q) zl[u][q] = eu[lane + 64 * q];
+              gl[u] = eu[gl_off];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
+#pragma unroll
+              for (int q = 0; q < RB; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
+              rw = __builtin_fma(y, gl[u], rw);
+            }
+          }
+        };
+        accum(std::integral_constant<int, 1>{}, 0, neva);
+        if (nevd > 0) accum(std::integral_constant<int, -1>{}, KEV - 1, nevd);
+        const double delta = __builtin_fma(pa2, bcast(z, pj2), pa1 * bcast(z, pj1));
+        const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
+        const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
+        if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
+        const bool dep = !(delta > 1e-11 * cn);
+        const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
+        double ratio = __builtin_inf();
+        if (wcid >= 0 && rw > 0.0) {
+          const double qv = lam * fast_rcp(rw);
+          ratio = qv > 0.0 ? qv : 0.0;
+        }
+        double t1 = __builtin_inf();
+        int l = -1;
+        if (khw > 0) {
+          t1 = wave_min_pos_f64(ratio);
+          if (t1 < __builtin_inf()) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
+        }
+        const double t = (t2 <= t1) ? t2 : t1;
+        if (!(t < __builtin_inf())) {
+          status |= QMPC_DEV_ST_INFEASIBLE;
+          break;
+        }
+        if (!dep) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
+        }
+        lam -= t * rw;
+        lp += t;
+        iters += 1;
+        if (t2 <= t1) {
+          // ---- full step: p joins the working set in the first free slot (an add event)
+          const unsigned long long fm = __ballot(lane < KS && wcid < 0);
+          const int qslot = fm ? __ffsll((long long)fm) - 1 : -1;
+          if (qslot < 0 || ((neva + 4) & ~3) + ((nevd + 3) & ~3) > KEV) {
+            retry = true;  // out of room: the robot is re-run with the Schur-form engine
+            break;
+          }
+          const double s = rsqrt_full(delta);
+          double* en = pool + neva * EV;
+#pragma unroll
+          for (int q = 0; q < RB; ++q) en[lane + 64 * q] = z[q] * s;
+          if (lane < KS) en[NP + lane] = (lane == qslot) ? s : ((wcid >= 0) ? -rw * s : 0.0);
+          if (lane == qslot) {
+            wcid = p_e;
+            lam = lp;
+          }
+          if (lane == psl) amask |= (1u << pty);
+          khw = (qslot + 1 > khw) ? qslot + 1 : khw;
+          neva += 1;
+          need_p = true;
+        } else {
+          // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event)
+          if (((neva + 3) & ~3) + ((nevd + 4) & ~3) > KEV) {
+            retry = true;
+            break;
+          }
+          // u = N*_l (index-major lanes), sc = S^-1[:, l] (slot lanes)
+          double u[RB], sc = 0.0;
+#pragma unroll
+          for (int q = 0; q < RB; ++q) u[q] = 0.0;
+          auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
+            constexpr int DIR = decltype(dirc)::value;
+            for (int t0 = 0; t0 < cnt; t0 += 4) {
+              const double* ev = pool + (base + DIR * t0) * EV;
+              double gll[4], zl[4][RB], gw[4];
+#pragma unroll
+              for (int u4 = 0; u4 < 4; ++u4) {
+                const double* eu = ev + DIR * u4 * EV;
+                gll[u4] = eu[NP + l];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) zl[u4][q] = eu[lane + 64 * q];
+                gw[u4] = eu[gl_off];
+              }
+#pragma unroll
+              for (int u4 = 0; u4 < 4; ++u4) {
+#pragma unroll
+                for (int q = 0; q < RB; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
+                sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
+              }
+            }
+          };
+          dacc(std::integral_constant<int, 1>{}, 0, neva);
+          if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
+          const double gamma = readlane_f64(sc, l);
+          if (!(gamma > 0.0)) {
+            retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
+            break;
+          }
+          const double sg = rsqrt_full(gamma);
+          const int de = __builtin_amdgcn_readlane(wcid, l);
+          double* en = pool + (KEV - 1 - nevd) * EV;
+#pragma unroll
+          for (int q = 0; q < RB; ++q) en[lane + 64 * q] = u[q] * sg;
+          if (lane < KS) en[NP + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
+          // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
+          if (lane < neva) pool[lane * EV + NP + l] = 0.0;
+          if (lane < nevd) pool[(KEV - 1 - lane) * EV + NP + l] = 0.0;
+          if (lane == l) {
+            wcid = -1;
+            lam = 0.0;
+          }
+          if (lane == de / 5) amask &= ~(1u << (de % 5));
+          nevd += 1;
+        }
+        __builtin_amdgcn_wave_barrier();
         if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
-        if (lane == 0) S.mode = mode;
       }
-      __syncthreads();  // ---- A: the command is published
-      if (dbg_clk && tid == 0 && iters == 1) dbg_clk[11] = clock64();
-      const int mode = S.mode;
-      if (mode == M_DONE) break;
-      if (mode == M_ADD) {
-        const int qs = S.u_q, kn = S.u_kn;
-        const double dinv = S.u_s;
-        rank1(Sb.zb, -dinv);  // P -= z z^T / delta
-        if (irow < n) {
-          const double zi = Sb.zb[irow] * dinv;
-          // N*_w -= z r_w / delta ; N*_q = z / delta
-          for (int w0 = part; w0 < kn; w0 += 8) {
-            const int w1 = w0 + 4;
-            double* nr0 = n_row(w0);
-            double* nr1 = n_row(w1 < kn ? w1 : w0);
-            const double o0 = nr0[irow], o1 = nr1[irow], r0v = Sb.rb[w0], r1v = Sb.rb[w1 < kn ? w1 : w0];
-            nr0[irow] = (w0 == qs) ? zi : __builtin_fma(-zi, r0v, o0);
-            if (w1 < kn) nr1[irow] = (w1 == qs) ? zi : __builtin_fma(-zi, r1v, o1);
-          }
-        }
-        // S^-1 bordered update: S[a][b] += r_a r_b/delta ; S[q][a] = -r_a/delta ; S[q][q] = 1/delta
-        if (irow < kn) {
-          const int lo = irow;
-          const double rlo = Sb.rb[lo];
-          for (int hi = lo + part; hi < kn; hi += 4) {
-            const int idx = hi * (hi + 1) / 2 + lo;
-            const double rhi = Sb.rb[hi];
-            double v;
-            if (hi == qs && lo == qs) v = dinv;
-            else if (hi == qs) v = -rlo * dinv;
-            else if (lo == qs) v = -rhi * dinv;
-            else v = __builtin_fma(rhi * dinv, rlo, Sb.Sinv[idx]);
-            Sb.Sinv[idx] = v;
-          }
-        }
-        if (dbg_clk && tid == 0 && iters == 1) dbg_clk[12] = clock64();
-        __syncthreads();  // ---- B
-        if (dbg_clk && tid == 0 && iters == 1) dbg_clk[13] = clock64();
-        if (tid == 0) Sb.rb[qs] = 0.0;  // a fresh slot has r = 0 until it is computed again
-      } else {  // M_DROP
-        const int l = S.u_l, kn = S.u_kn;
-        const double ginv = S.u_s;  // 1 / S^-1[l][l]
-        const double* ul = n_row(l);
-        rank1(ul, ginv);  // P += u u^T / S^-1[l][l]
-        __syncthreads();  // u (row l of N*) is read by everybody above, rewritten below
-        if (irow < n) {
-          const double ui = ul[irow] * ginv;
-          // N*_w -= u S^-1[w][l] / S^-1[l][l]   (w != l)
-          for (int w = part; w < kn; w += 4)
-            if (w != l) {
-              double* nr = n_row(w);
-              nr[irow] = __builtin_fma(-ui, Sb.Sinv[sym_idx(w, l)], nr[irow]);
-            }
-        }
-        // S' = S - S[:,l] S[l,:] / S[l][l] on the other slots
-        if (irow < kn && irow != l) {
-          const int lo = irow;
-          const double slo = Sb.Sinv[sym_idx(l, lo)] * ginv;
-          for (int hi = lo + part; hi < kn; hi += 4)
-            if (hi != l) {
-              const int idx = hi * (hi + 1) / 2 + lo;
-              Sb.Sinv[idx] = __builtin_fma(-slo, Sb.Sinv[sym_idx(hi, l)], Sb.Sinv[idx]);
-            }
-        }
-        __syncthreads();  // ---- B
-        if (tid < kn) Sb.Sinv[sym_idx(tid, l)] = 0.0;
-        if (tid == 0) Sb.rb[l] = 0.0;
-        if (irow < n && part == 0) n_row(l)[irow] = 0.0;
-        __syncthreads();
-      }
-    }
-    if (engine) {
       __builtin_amdgcn_s_setprio(0);
       QMPC_TICK(6);
       if (!retry) {

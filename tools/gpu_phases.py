@@ -49,3 +49,7 @@ ok = (it > 0) & (c[:, 13] > 0) & (c[:, 8] > 0)
 if ok.any():
     print("  v5 first iteration (tid 0, median): select %d | z,r,delta %d | step+publish %d | barrier A %d | parallel update %d | barrier B %d" % tuple(
         np.median(x[ok]) for x in (c[:,8]-c[:,5], c[:,9]-c[:,8], c[:,10]-c[:,9], c[:,11]-c[:,10], c[:,12]-c[:,11], c[:,13]-c[:,12])))
+    ok2 = ok & (c[:, 14] > 0) & (c[:, 15] > 0)
+    if ok2.any():
+        print("  v5 first update (wave 1, median, since barrier A seen by tid 0): rank1 done %d | N*,S^-1 done %d" % tuple(
+            np.median(x[ok2]) for x in (c[:,14]-c[:,11], c[:,15]-c[:,11])))
