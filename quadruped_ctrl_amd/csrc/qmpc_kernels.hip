@@ -102,6 +102,35 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
+// a[j] += c[lane j of this lane's row of 16] * u for j = 0..15: sixteen DP-ALU DPP
+// fmacs (row_newbcast), i.e. the 16 wave-uniform pivot-column values are held one
+// per lane and broadcast inside the instruction instead of being re-read from LDS
+// by every lane.  One asm block: the leading s_nop covers the VALU-write -> DPP-read
+// hazard that the compiler cannot see through inline asm.
+__device__ __forceinline__ void fmac16_rowbcast(double (&a)[16], double c, double u) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %12, %16, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %13, %16, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %14, %16, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %15, %16, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+        "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+      : "v"(c), "v"(u));
+}
+
 // compile-time loop: f(integral_constant<int, R>) for R = 0 .. N-1, so that
 // register-array indices derived from R are constant expressions
 template <int R, int N>
@@ -188,6 +217,7 @@ struct Smem {
       } a;
       struct Swp {  // sweep + unconstrained minimiser (stages 2-4)
         alignas(16) double colbuf[2][2][C::NP + 2];  // [parity][column of the pair][row]
+        double ubuf[2][2][C::NP];  // class 1: F columns (pivot-row correction folded in), same buffering
         double g[C::NP];
         double part[4][C::NP];
       } w;
@@ -551,7 +581,64 @@ __device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
   // (P^-1 C^T); since a_kj == c_j they get it from the same update with
   // F_k = I - P^-1, so the update has no row special-casing.
   bool notpd = false;
-  {
+  if constexpr (RB == 1) {
+    // Class 1: a column group is exactly one wave (lane == row), so the wave that
+    // owns the NEXT pivot pair reads its 2x2 pivot block with readlane, inverts it
+    // once, and publishes F = C P^-1 (with the pivot-row correction folded in) next
+    // to the pivot columns.  The other three waves only load and do the 2 fma per
+    // element: the reciprocal and the F arithmetic are not replicated 4x.
+    double sv0 = 0.0, sv1 = 0.0;  // pivot-column registers' new values, kept by the producing wave
+    auto produce = [&](double c0n, double c1n, int k0n, int mn) __attribute__((always_inline)) {
+      const int k1n = k0n + 1;  // k1n == n: identity padding column, a no-op pivot
+      const double d0 = readlane_f64(c0n, k0n);
+      const double e = readlane_f64(c0n, k1n);  // A[k1][k0]
+      const double d1p = readlane_f64(c1n, k1n);
+      // 2x2 pivot block P = [[d0, e], [e, d1p]] inverted through its determinant:
+      // ONE reciprocal on the critical path.  P^-1 = idet [[d1p, -e], [-e, d0]].
+      const double det = __builtin_fma(d0, d1p, -e * e);
+      notpd |= !(d0 > 0.0) | !(det > 0.0);
+      const double idet = fast_rcp(det);
+      const double i11 = d1p * idet, i01 = e * idet, i00 = d0 * idet;  // +-entries of P^-1
+      // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
+      const double fg0 = __builtin_fma(i11, c0n, -i01 * c1n);
+      const double fg1 = __builtin_fma(i00, c1n, -i01 * c0n);
+      const bool p0 = (i == k0n), p1 = (i == k1n);
+      // pivot columns <- F, pivot block <- -P^-1
+      sv0 = p0 ? -i11 : (p1 ? i01 : fg0);
+      sv1 = p0 ? i01 : (p1 ? -i00 : fg1);
+      // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
+      Sw.colbuf[mn & 1][0][i] = c0n;
+      Sw.colbuf[mn & 1][1][i] = c1n;
+      Sw.ubuf[mn & 1][0][i] = -(fg0 + (p0 ? -i11 : (p1 ? i01 : 0.0)));  // stored negated: the update is a += c * (-F)
+      Sw.ubuf[mn & 1][1][i] = -(fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0)));
+    };
+    if (c == 0) produce(a[0], a[1], 0, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {
+      StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
+        constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
+        constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
+        const int k0 = kb * CW + r0;
+        if (k0 < n) {
+          const int m = k0 >> 1;
+          // lane l holds pivot-column entry c*16 + l%16 (the 16 columns of this wave)
+          const double cv0 = Sw.colbuf[m & 1][0][c * CW + (lane & 15)];
+          const double cv1 = Sw.colbuf[m & 1][1][c * CW + (lane & 15)];
+          const double nu0 = Sw.ubuf[m & 1][0][i], nu1 = Sw.ubuf[m & 1][1][i];  // -F_i0, -F_i1
+          fmac16_rowbcast(a, cv0, nu0);
+          fmac16_rowbcast(a, cv1, nu1);
+          if (c == kb) {
+            a[r0] = sv0;
+            a[r1] = sv1;
+          }
+          const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
+          if (k0 + 2 < n && c == kbn) produce(a[rn0], a[rn1], k0 + 2, m + 1);
+          __syncthreads();
+        }
+      });
+    }
+  } else {
     if (c == 0) {
       Sw.colbuf[0][0][i] = a[0];
       Sw.colbuf[0][1][i] = a[1];
