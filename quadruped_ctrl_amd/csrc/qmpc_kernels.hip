@@ -671,11 +671,15 @@ __device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
           // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
           const double u0 = fg0 + (p0 ? -i11 : (p1 ? i01 : 0.0));
           const double u1 = fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0));
+          // the CW pivot-column values of this column group, 16 per register (one per
+          // lane of a row), broadcast inside the DPP fmac -- see fmac16_rowbcast
 #pragma unroll
-          for (int jj = 0; jj < CW; ++jj) {
-            a[jj] = __builtin_fma(-u1, cb1[c * CW + jj], __builtin_fma(-u0, cb0[c * CW + jj], a[jj]));
-            if constexpr (RB >= 3)  // 96 matrix registers: keep the column loads from being hoisted wholesale
-              if ((jj & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+          for (int g = 0; g < CW / 16; ++g) {
+            const double cv0 = cb0[c * CW + 16 * g + (lane & 15)];
+            const double cv1 = cb1[c * CW + 16 * g + (lane & 15)];
+            double(&ag)[16] = *reinterpret_cast<double(*)[16]>(&a[16 * g]);
+            fmac16_rowbcast(ag, cv0, -u0);
+            fmac16_rowbcast(ag, cv1, -u1);
           }
           if (c == kb) {
             // pivot columns <- F, pivot block <- -P^-1
