@@ -251,11 +251,10 @@ struct Smem {
 // Schur form that never overflows.  Returns true when the robot must be re-run
 // with the other engine.
 template <int RB, bool V5>
-__device__ bool solve_one(const int rid, Smem<RB>& S, const QmpcParams& PK) {
+__device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW;
   const QmpcParams& P = S.par;  // parked copy: everything after stage 0
-  const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int i = tid % NP;  // matrix row owned by this thread
   const int c = tid / NP;  // column group (0..3): columns c*CW .. c*CW+CW-1
@@ -1411,14 +1410,18 @@ __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void q
   if constexpr (RB < 3) {
     // projected-inverse engine first; the (rare) robot that runs out of pool is
     // solved again from scratch with the Schur-form engine, which cannot overflow
-    if (solve_one<RB, true>(rid, S, P)) {
+    if (solve_one<RB, true>(rid, (int)threadIdx.x, S, P)) {
       __syncthreads();
-      solve_one<RB, false>(rid, S, P);
+      // opaque thread id: without it the compiler keeps per-thread values of the
+      // first run alive (spilled to scratch by EVERY workgroup) for this rare second run
+      int tid2 = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid2));
+      solve_one<RB, false>(rid, tid2, S, P);
       __syncthreads();
       if (threadIdx.x == 0) P.status[rid] |= QMPC_DEV_ST_FALLBACK;  // informational
     }
   } else {
-    solve_one<RB, false>(rid, S, P);
+    solve_one<RB, false>(rid, (int)threadIdx.x, S, P);
   }
 }
 
