@@ -131,6 +131,20 @@ __device__ __forceinline__ void fmac16_rowbcast(double (&a)[16], double c, doubl
       : "v"(c), "v"(u));
 }
 
+// the same for four accumulators a[J0 .. J0+3] (lets the producing wave of the
+// sweep interleave its pivot arithmetic with the update)
+template <int J0>
+__device__ __forceinline__ void fmac4_rowbcast(double (&a)[16], double c, double u) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+      : "+v"(a[J0]), "+v"(a[J0 + 1]), "+v"(a[J0 + 2]), "+v"(a[J0 + 3])
+      : "v"(c), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3));
+}
+
 // compile-time loop: f(integral_constant<int, R>) for R = 0 .. N-1, so that
 // register-array indices derived from R are constant expressions
 template <int R, int N>
@@ -587,37 +601,65 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     // to the pivot columns.  The other three waves only load and do the 2 fma per
     // element: the reciprocal and the F arithmetic are not replicated 4x.
     double sv0 = 0.0, sv1 = 0.0;  // pivot-column registers' new values, kept by the producing wave
-    auto produce = [&](double c0n, double c1n, int k0n, int mn) __attribute__((always_inline)) {
-      const int k1n = k0n + 1;  // k1n == n: identity padding column, a no-op pivot
-      const double d0 = readlane_f64(c0n, k0n);
-      const double e = readlane_f64(c0n, k1n);  // A[k1][k0]
-      const double d1p = readlane_f64(c1n, k1n);
-      // 2x2 pivot block P = [[d0, e], [e, d1p]] inverted through its determinant:
-      // ONE reciprocal on the critical path.  P^-1 = idet [[d1p, -e], [-e, d0]].
-      const double det = __builtin_fma(d0, d1p, -e * e);
-      notpd |= !(d0 > 0.0) | !(det > 0.0);
-      const double idet = fast_rcp(det);
-      const double i11 = d1p * idet, i01 = e * idet, i00 = d0 * idet;  // +-entries of P^-1
-      // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
-      const double fg0 = __builtin_fma(i11, c0n, -i01 * c1n);
-      const double fg1 = __builtin_fma(i00, c1n, -i01 * c0n);
-      const bool p0 = (i == k0n), p1 = (i == k1n);
-      // pivot columns <- F, pivot block <- -P^-1
-      sv0 = p0 ? -i11 : (p1 ? i01 : fg0);
-      sv1 = p0 ? i01 : (p1 ? -i00 : fg1);
-      // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
-      Sw.colbuf[mn & 1][0][i] = c0n;
-      Sw.colbuf[mn & 1][1][i] = c1n;
-      Sw.ubuf[mn & 1][0][i] = -(fg0 + (p0 ? -i11 : (p1 ? i01 : 0.0)));  // stored negated: the update is a += c * (-F)
-      Sw.ubuf[mn & 1][1][i] = -(fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0)));
+    // the pivot arithmetic in stages, so that the producing wave can slot the rest
+    // of its update into the latencies of this dependent chain
+    double pd0, pe, pd1, pdet, px, pc0, pc1;
+    auto prod_read = [&](double c0n, double c1n, int k0n) __attribute__((always_inline)) {
+      pc0 = c0n;
+      pc1 = c1n;
+      pd0 = readlane_f64(c0n, k0n);
+      pe = readlane_f64(c0n, k0n + 1);   // A[k1][k0]   (k1 == n: identity padding column, a no-op pivot)
+      pd1 = readlane_f64(c1n, k0n + 1);
     };
-    if (c == 0) produce(a[0], a[1], 0, 0);
+    // 2x2 pivot block P = [[d0, e], [e, d1]] inverted through its determinant:
+    // ONE reciprocal on the critical path.  P^-1 = idet [[d1, -e], [-e, d0]].
+    auto prod_det = [&]() __attribute__((always_inline)) {
+      pdet = __builtin_fma(pd0, pd1, -pe * pe);
+      notpd |= !(pd0 > 0.0) | !(pdet > 0.0);
+    };
+    auto prod_rcp = [&]() __attribute__((always_inline)) { px = __builtin_amdgcn_rcp(pdet); };
+    auto prod_newton = [&]() __attribute__((always_inline)) {
+      const double e1 = __builtin_fma(-pdet, px, 1.0);
+      px = __builtin_fma(px, e1, px);
+    };
+    double pfg0, pfg1, pq0, pq1;  // F_i0, F_i1 and the pivot-row corrections of this row
+    auto prod_fg = [&](int k0n) __attribute__((always_inline)) {
+      const double i11 = pd1 * px, i01 = pe * px, i00 = pd0 * px;  // +-entries of P^-1
+      // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
+      pfg0 = __builtin_fma(i11, pc0, -i01 * pc1);
+      pfg1 = __builtin_fma(i00, pc1, -i01 * pc0);
+      const bool p0 = (i == k0n), p1 = (i == k0n + 1);
+      pq0 = p0 ? -i11 : (p1 ? i01 : 0.0);
+      pq1 = p0 ? i01 : (p1 ? -i00 : 0.0);
+    };
+    auto prod_store = [&](int k0n, int mn) __attribute__((always_inline)) {
+      const bool pr = (i == k0n) | (i == k0n + 1);
+      // pivot columns <- F, pivot block <- -P^-1
+      sv0 = pr ? pq0 : pfg0;
+      sv1 = pr ? pq1 : pfg1;
+      // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
+      Sw.colbuf[mn & 1][0][i] = pc0;
+      Sw.colbuf[mn & 1][1][i] = pc1;
+      Sw.ubuf[mn & 1][0][i] = -(pfg0 + pq0);  // stored negated: the update is a += c * (-F)
+      Sw.ubuf[mn & 1][1][i] = -(pfg1 + pq1);
+    };
+    if (c == 0) {
+      prod_read(a[0], a[1], 0);
+      prod_det();
+      prod_rcp();
+      prod_newton();
+      prod_newton();
+      prod_fg(0);
+      prod_store(0, 0);
+    }
     __syncthreads();
+#define QMPC_PIN __builtin_amdgcn_sched_barrier(0)
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
       StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
         constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
         constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
+        constexpr int G0 = 4 * (rn0 / 4), G1 = (G0 + 4) % 16, G2 = (G0 + 8) % 16, G3 = (G0 + 12) % 16;
         const int k0 = kb * CW + r0;
         if (k0 < n) {
           const int m = k0 >> 1;
@@ -625,18 +667,51 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           const double cv0 = Sw.colbuf[m & 1][0][c * CW + (lane & 15)];
           const double cv1 = Sw.colbuf[m & 1][1][c * CW + (lane & 15)];
           const double nu0 = Sw.ubuf[m & 1][0][i], nu1 = Sw.ubuf[m & 1][1][i];  // -F_i0, -F_i1
-          fmac16_rowbcast(a, cv0, nu0);
-          fmac16_rowbcast(a, cv1, nu1);
-          if (c == kb) {
-            a[r0] = sv0;
-            a[r1] = sv1;
-          }
+          const double so0 = sv0, so1 = sv1;
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
-          if (k0 + 2 < n && c == kbn) produce(a[rn0], a[rn1], k0 + 2, m + 1);
+          if (k0 + 2 < n && c == kbn) {
+            // this wave owns the next pivot pair: its two columns first, then the
+            // pivot-block inverse interleaved with the other twelve columns
+            fmac4_rowbcast<G0>(a, cv0, nu0);
+            fmac4_rowbcast<G0>(a, cv1, nu1);
+            QMPC_PIN;
+            prod_read(a[rn0], a[rn1], k0 + 2);
+            QMPC_PIN;
+            fmac4_rowbcast<G1>(a, cv0, nu0);
+            QMPC_PIN;
+            prod_det();
+            prod_rcp();
+            QMPC_PIN;
+            fmac4_rowbcast<G1>(a, cv1, nu1);
+            QMPC_PIN;
+            prod_newton();
+            QMPC_PIN;
+            fmac4_rowbcast<G2>(a, cv0, nu0);
+            QMPC_PIN;
+            prod_newton();
+            QMPC_PIN;
+            fmac4_rowbcast<G2>(a, cv1, nu1);
+            QMPC_PIN;
+            prod_fg(k0 + 2);
+            QMPC_PIN;
+            fmac4_rowbcast<G3>(a, cv0, nu0);
+            QMPC_PIN;
+            prod_store(k0 + 2, m + 1);
+            QMPC_PIN;
+            fmac4_rowbcast<G3>(a, cv1, nu1);
+          } else {
+            fmac16_rowbcast(a, cv0, nu0);
+            fmac16_rowbcast(a, cv1, nu1);
+          }
+          if (c == kb) {
+            a[r0] = so0;
+            a[r1] = so1;
+          }
           __syncthreads();
         }
       });
     }
+#undef QMPC_PIN
   } else {
     if (c == 0) {
       Sw.colbuf[0][0][i] = a[0];
