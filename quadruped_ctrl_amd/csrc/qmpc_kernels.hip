@@ -850,7 +850,11 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       constexpr int KS = C::KS, EV = NP + KS, KEV = (C::NPOOL / EV) & ~3;
       double* const pool = Sb.Sinv;
       const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
-      const int max_iter = P.max_iter;
+      const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
+      // wave-uniform predicate -> scalar branch (the operands are uniform but live in
+      // VGPRs; a ballot gives the compiler an SGPR condition, so the loop state
+      // below stays in SGPRs instead of being carried through exec masks)
+      auto uni = [](bool cnd) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(cnd) != 0ull; };
       unsigned amask = 0;  // stance-slot lane: bit ty = constraint (slot, ty) is in the working set
       int wcid = -1;       // working-slot lane: constraint id in slot `lane`, -1 = free
       double lam = 0.0;    // ... and its multiplier
@@ -892,7 +896,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       __builtin_amdgcn_s_setprio(3);  // the serial part of the workgroup: win issue arbitration
 
       while (true) {
-        if (need_p) {
+        if (uni(need_p)) {
           // ---- most violated constraint outside the working set (normalised), or done
           unsigned key = 0;
           const int j0 = 3 * (lane < nst ? lane : 0);
@@ -937,6 +941,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         // z -= +-y z~ , r += y g~
         auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
           constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
+#pragma unroll 1
           for (int t0 = 0; t0 < cnt; t0 += 4) {
             const double* ev = pool + (base + DIR * t0) * EV;
             double ya[4], yb[4], zl[4][RB], gl[4];
@@ -964,7 +969,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
         const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
-        const bool dep = !(delta > 1e-11 * cn);
+        const bool dep = uni(!(delta > 1e-11 * cn));
         const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
         double ratio = __builtin_inf();
         if (wcid >= 0 && rw > 0.0) {
@@ -975,10 +980,10 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         int l = -1;
         if (khw > 0) {
           t1 = wave_min_pos_f64(ratio);
-          if (t1 < __builtin_inf()) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
+          if (uni(t1 < __builtin_inf())) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
         }
         const double t = (t2 <= t1) ? t2 : t1;
-        if (!(t < __builtin_inf())) {
+        if (uni(!(t < __builtin_inf()))) {
           status |= QMPC_DEV_ST_INFEASIBLE;
           break;
         }
@@ -989,7 +994,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         lam -= t * rw;
         lp += t;
         iters += 1;
-        if (t2 <= t1) {
+        if (uni(t2 <= t1)) {
           // ---- full step: p joins the working set in the first free slot (an add event)
           const unsigned long long fm = __ballot(lane < KS && wcid < 0);
           const int qslot = fm ? __ffsll((long long)fm) - 1 : -1;
@@ -1022,6 +1027,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           for (int q = 0; q < RB; ++q) u[q] = 0.0;
           auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;
+#pragma unroll 1
             for (int t0 = 0; t0 < cnt; t0 += 4) {
               const double* ev = pool + (base + DIR * t0) * EV;
               double gll[4], zl[4][RB], gw[4];
@@ -1044,7 +1050,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           dacc(std::integral_constant<int, 1>{}, 0, neva);
           if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
           const double gamma = readlane_f64(sc, l);
-          if (!(gamma > 0.0)) {
+          if (uni(!(gamma > 0.0))) {
             retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
             break;
           }
