@@ -56,27 +56,26 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   t = dpp_u32<0x143, 0xc>(0u, v); v = v > t ? v : t;
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-// min over the wave of NON-NEGATIVE doubles (bit pattern order == value order)
+// min over the 64 lanes of a wave, result uniform
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  unsigned t;
+  t = dpp_u32<0x111, 0xf>(~0u, v); v = v < t ? v : t;
+  t = dpp_u32<0x112, 0xf>(~0u, v); v = v < t ? v : t;
+  t = dpp_u32<0x114, 0xf>(~0u, v); v = v < t ? v : t;
+  t = dpp_u32<0x118, 0xf>(~0u, v); v = v < t ? v : t;
+  t = dpp_u32<0x142, 0xa>(~0u, v); v = v < t ? v : t;
+  t = dpp_u32<0x143, 0xc>(~0u, v); v = v < t ? v : t;
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// min over the wave of NON-NEGATIVE doubles (bit pattern order == value order):
+// two 32-bit reductions (high words, then the low words of the lanes that tie on
+// the high word) instead of one 64-bit compare/select ladder
 __device__ __forceinline__ double wave_min_pos_f64(double x) {
-  unsigned long long v = (unsigned long long)__double_as_longlong(x);
-  const unsigned long long ident = ~0ull;
-#define QMPC_MIN_STEP(CTRL, RM)                                                          \
-  {                                                                                      \
-    const unsigned lo = dpp_u32<CTRL, RM>((unsigned)ident, (unsigned)v);                 \
-    const unsigned hi = dpp_u32<CTRL, RM>((unsigned)(ident >> 32), (unsigned)(v >> 32)); \
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;                    \
-    v = o < v ? o : v;                                                                   \
-  }
-  QMPC_MIN_STEP(0x111, 0xf)
-  QMPC_MIN_STEP(0x112, 0xf)
-  QMPC_MIN_STEP(0x114, 0xf)
-  QMPC_MIN_STEP(0x118, 0xf)
-  QMPC_MIN_STEP(0x142, 0xa)
-  QMPC_MIN_STEP(0x143, 0xc)
-#undef QMPC_MIN_STEP
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mhi = wave_min_u32(hi);
+  const unsigned mlo = wave_min_u32(hi == mhi ? lo : ~0u);
+  return __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
 }
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -896,6 +895,17 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       __builtin_amdgcn_s_setprio(3);  // the serial part of the workgroup: win issue arbitration
 
       while (true) {
+        // loop-carried counters are wave-uniform: keep them in SGPRs
+        iters = __builtin_amdgcn_readfirstlane(iters);
+        khw = __builtin_amdgcn_readfirstlane(khw);
+        neva = __builtin_amdgcn_readfirstlane(neva);
+        nevd = __builtin_amdgcn_readfirstlane(nevd);
+        status = __builtin_amdgcn_readfirstlane(status);
+        p_e = __builtin_amdgcn_readfirstlane(p_e);
+        psl = __builtin_amdgcn_readfirstlane(psl);
+        pty = __builtin_amdgcn_readfirstlane(pty);
+        pj1 = __builtin_amdgcn_readfirstlane(pj1);
+        pj2 = __builtin_amdgcn_readfirstlane(pj2);
         if (uni(need_p)) {
           // ---- most violated constraint outside the working set (normalised), or done
           unsigned key = 0;
