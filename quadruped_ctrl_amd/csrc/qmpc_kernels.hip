@@ -18,12 +18,16 @@
 //     and every B_p^T W B_q has a closed form in the 3x3 blocks
 //     M_b = I_w^-1 [r_b]x, N_b = R_yaw^T M_b -- no 13h x 12h B_qp is ever formed
 //     (the reference multiplies it densely, SolverMPC.cpp:395).
-//   * inversion by n_r symmetric Gauss-Jordan sweeps, software-pipelined so the
-//     next pivot column is published before the rank-1 update of the current
-//     one is finished (one barrier per pivot); then a Goldfarb-Idnani dual
+//   * inversion by symmetric Gauss-Jordan sweeps, two pivots per barrier; the
+//     pivot columns are held one value per lane and broadcast INSIDE the fp64
+//     fmac (DP-ALU DPP, row_newbcast) instead of being re-read from LDS by every
+//     lane; in class 1 the wave that owns the next pivot pair inverts the 2x2
+//     pivot block once for the whole block.  Then a Goldfarb-Idnani dual
 //     active-set on the explicit inverse, run by wave 0 out of registers
-//     (lane = stance foot-step / working-set slot).  Swing feet are eliminated
-//     up front exactly like SolverMPC.cpp:441-525.
+//     (lane = variable / stance foot-step / working-set slot) with the
+//     projected inverse kept as a sum of rank-1 events (no in-place updates, no
+//     barrier in the loop).  Swing feet are eliminated up front exactly like
+//     SolverMPC.cpp:441-525.
 //   * fp64 throughout the solve (the reference hands fp32-assembled data to a
 //     double-precision qpOASES; fp64 assembly removes the fp32 rounding noise
 //     instead of adding a second, uncorrelated copy of it).
@@ -37,6 +41,9 @@
 namespace {
 
 constexpr int WAVE = 64;
+#ifndef QMPC_ENGINE_PRIO
+#define QMPC_ENGINE_PRIO 3
+#endif
 
 // ----------------------------------------------------------------- wave helpers
 // DPP control words (gfx9): row_shr:n = 0x110+n, row_bcast:15 = 0x142,
@@ -197,9 +204,11 @@ struct Cfg {
   static constexpr int KW = (KMAX + 63) / 64;  // slots per engine lane
   static constexpr int NS = KMAX * (KMAX + 1) / 2;
   static constexpr int NH = NP * (NP + 1) / 2;
-  // v5 engine: doubles shared by the packed S_W^-1 (front) and the rows of N* (back);
-  // sized so that class 1 keeps 4 workgroups per CU
-  static constexpr int POOL = (RB == 1) ? 2496 : (RB == 2 ? 11400 : NS);
+  // doubles of active-set storage behind the packed inverse.  Event-form engine:
+  // one (z~, g~) record of NP + KS doubles per working-set change; Schur-form
+  // engine: packed S_W^-1 (front) and rows H^-1 c_w (back).  Sized so that
+  // class 1 keeps 4 workgroups per CU
+  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : NS);
   static constexpr int NPOOL = POOL > NS ? POOL : NS;
   static constexpr int KS = (RB == 1) ? 32 : 64;  // event-form engine: working-set slot capacity (one per lane)
 };
@@ -212,8 +221,7 @@ struct Smem {
   double fmaxk[64];
   unsigned char sidx[64];
   int nst, status;
-  int mode, u_q, u_kn, u_l;  // v5 engine: block-wide update command
-  double u_s;                // ... and its scalar (1/delta or 1/S_ll)
+  int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   // ---- phase-local storage
   union U {
     struct AW {
@@ -237,13 +245,13 @@ struct Smem {
     } aw;
     struct Slv {  // active-set solve (stage 5): the engine wave's working storage
       double Hp[C::NH];    // H^-1, packed lower triangle: (i,j), i >= j, at i(i+1)/2 + j
-      // pool: (C_W^T H^-1 C_W)^-1 packed the same way, growing from the front with
-      // the slot high-water mark; rows M[w] = H^-1 c_w (NP doubles each) from the
-      // back while they fit (beyond that they are recomputed from Hp)
+      // pool.  Event-form engine: records (z~[NP], g~[KS]), add events from the
+      // front and drop events from the back.  Schur-form engine: (C_W^T H^-1 C_W)^-1
+      // packed like Hp, growing from the front with the slot high-water mark, and
+      // rows M[w] = H^-1 c_w (NP doubles each) from the back while they fit
+      // (beyond that they are recomputed from Hp)
       double Sinv[C::NPOOL];
-      // v5 engine: diag(H^-1), the published step z / dual step r of the current update
-      double D[C::NP], zb[C::NP], rb[C::KMAX];
-      double dummy[64];  // sink for predicated-off LDS updates
+      double D[C::NP];  // event-form engine: diag(H^-1)
     } b;
   } u;
 };
@@ -259,10 +267,10 @@ struct Smem {
     if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); \
   } while (0)
 
-// V5 selects the active-set engine: true = projected-inverse form (all waves
-// update P, N*, S^-1 in parallel; capacity-limited), false = the single-wave
-// Schur form that never overflows.  Returns true when the robot must be re-run
-// with the other engine.
+// V5 selects the active-set engine: true = event form (projected inverse as a
+// sum of rank-1 events; fastest, capacity-limited by the LDS pool), false = the
+// Schur form that never overflows.  Both are run by wave 0 alone.  Returns true
+// when the robot must be re-run with the other engine.
 template <int RB, bool V5>
 __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
@@ -892,7 +900,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         y = __builtin_fma(0.5 * y, e, y);
         return y;
       };
-      __builtin_amdgcn_s_setprio(3);  // the serial part of the workgroup: win issue arbitration
+      __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);  // the serial part of the workgroup: win issue arbitration
 
       while (true) {
         // loop-carried counters are wave-uniform: keep them in SGPRs
@@ -1120,7 +1128,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     const double inv_fr = P.inv_fr_norm;
     const double tol = P.tol;
     const int max_iter = P.max_iter;
-    __builtin_amdgcn_s_setprio(3);  // the serial part of the workgroup: win issue arbitration
+    __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);  // the serial part of the workgroup: win issue arbitration
     auto Hinv = [&](int r, int cidx) __attribute__((always_inline)) {
       const int hi = r > cidx ? r : cidx, lo = r > cidx ? cidx : r;
       return Sb.Hp[hi * (hi + 1) / 2 + lo];

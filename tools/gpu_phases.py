@@ -23,33 +23,22 @@ for k, nm in enumerate(names):
     print(f"  {nm:14s} {np.median(d[:,k]):9.0f} {d[:,k].mean():9.0f} {d[:,k].max():9.0f}")
 tot = c[:, 7] - c[:, 0]
 print(f"  total          {np.median(tot):9.0f} {tot.mean():9.0f} {tot.max():9.0f}")
-print(f"  kernel span (max end - min start) {c[:,7].max()-c[:,0].min():.0f} cycles; start spread {c[:,0].max()-c[:,0].min():.0f}")
 sel = it > 0
 if sel.any():
     print(f"  active-set cycles per iteration (blocks with it>0): {np.median(d[sel,5]/it[sel]):.0f}")
 
 ok = (it > 0) & (c[:, 10] > 0)
 if ok.any():
-    print("  first AS iteration (median cycles): select+hc %d | d,r,z %d | step+Sinv update %d" % (
+    print("  first AS iteration (median cycles): select %d | z, r, delta %d | ratio test, step, event write %d" % (
         np.median(c[ok, 8] - c[ok, 5]), np.median(c[ok, 9] - c[ok, 8]), np.median(c[ok, 10] - c[ok, 9])))
 order = np.argsort(c[:, 0])
 early, late = order[: len(order) // 2], order[len(order) // 2:]
 print("  blocks by start time: early-half median total %.0f (sweep %.0f) | late-half median total %.0f (sweep %.0f)" % (
     np.median(tot[early]), np.median(d[early, 3]), np.median(tot[late]), np.median(d[late, 3])))
-end = c[:, 7] - c[:, 0].min()
 qs = [50, 90, 99, 99.9, 100]
-print("  block END time (cycles since first start) percentiles", {q: int(np.percentile(end, q)) for q in qs})
 print("  iters percentiles", {q: int(np.percentile(it, q)) for q in qs}, " AS cycles by iters:",
       {int(k): int(np.median(d[it == k, 5])) for k in np.unique(it)[:16]})
 
 print("  stage 0 detail (tid 0): loads landed %d | compute %d | barrier %d ;  stage 2: g %d | H asm %d" % tuple(
     np.median(x) for x in (c[:,11]-c[:,0], c[:,12]-c[:,11], c[:,1]-c[:,12], c[:,13]-c[:,2], c[:,3]-c[:,13])))
 
-ok = (it > 0) & (c[:, 13] > 0) & (c[:, 8] > 0)
-if ok.any():
-    print("  v5 first iteration (tid 0, median): select %d | z,r,delta %d | step+publish %d | barrier A %d | parallel update %d | barrier B %d" % tuple(
-        np.median(x[ok]) for x in (c[:,8]-c[:,5], c[:,9]-c[:,8], c[:,10]-c[:,9], c[:,11]-c[:,10], c[:,12]-c[:,11], c[:,13]-c[:,12])))
-    ok2 = ok & (c[:, 14] > 0) & (c[:, 15] > 0)
-    if ok2.any():
-        print("  v5 first update (wave 1, median, since barrier A seen by tid 0): rank1 done %d | N*,S^-1 done %d" % tuple(
-            np.median(x[ok2]) for x in (c[:,14]-c[:,11], c[:,15]-c[:,11])))
