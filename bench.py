@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index")
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (override)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--caller-side", action="store_true",
+                    help="time command -> record (qmpc_pack) -> solve -> body-frame forces per step instead of the "
+                         "solve alone (SURVEY row a12 on the GPU; not the headline configuration)")
     ap.add_argument("--no-hint", action="store_true",
                     help="do not tell the solver the workload's max stance foot-steps (launch every size class)")
     args = ap.parse_args()
@@ -120,6 +123,23 @@ def main():
     o = mpc.alloc_outputs(per_gpu, full=False, iters=True)
     inp, out = mpc.make_args(d, o)
     stream = torch.cuda.current_stream(dev)
+    if args.caller_side:
+        # commands resident in HBM; the record is rebuilt on the GPU every step
+        cmd = workloads.make_commands(per_gpu, horizon=h, seed=20260928 + rank, stand_fraction=0.0, calm=True)
+        dcmd = mpc.upload_command(cmd)
+        rec = mpc.alloc_record(per_gpu)
+        inp, out = mpc.make_args(rec, o)
+        f_ff = torch.empty_like(o["grf"])
+        max_stance = int(max(np.minimum(cmd["gait_durations"], h).sum(1).max(), 1))
+        if not args.no_hint:
+            mpc.set_max_stance(max_stance)
+        solve_only = mpc.solve_async
+
+        def step_all(n, inp_, out_, stream_):
+            mpc.pack_async(dcmd, rec, stream_)
+            solve_only(n, inp_, out_, stream_)
+            mpc.forces_to_body_async(n, dcmd["r_body"], o["grf"], f_ff, stream_)
+        mpc.solve_async = step_all
 
     def sync_all():
         if dist is not None:
@@ -146,7 +166,7 @@ def main():
 
     status = o["status"].cpu().numpy()
     iters = o["iters"].cpu().numpy()
-    nst = (b["gait"] != 0).sum(1)
+    nst = ((rec["gait"].cpu().numpy() if args.caller_side else b["gait"]) != 0).sum(1)
     n_fail = int(((status & 15) != 0).sum())
 
     if rank == 0:
@@ -170,7 +190,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{args.config}]: batch={per_gpu} robots/GPU, "
+            "config": {"workload": ("caller-side pipeline (qmpc_pack + solve + forces_to_body), " if args.caller_side else "") +
+                                   f"BASELINE.json configs[{args.config}]: batch={per_gpu} robots/GPU, "
                                    f"horizon={h}, mean reduced QP size {3.0 * nst.mean():.1f} vars",
                        "batch_per_gpu": per_gpu, "horizon": h, "sharding": f"independent robots x{world}",
                        "mean_active_set_iters": float(iters.mean()), "failed": n_fail,

@@ -142,6 +142,70 @@ int qmpc_debug_ld(qmpc_handle h);
  * the kernel's phase boundaries (NULL = off). */
 int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);
 
+/* ---------------------------------------------------------------------------
+ * Caller side of the solve, batched (SURVEY.md row a12 and the consumer of
+ * a11).  One row per robot in every array, DEVICE pointers.
+ *
+ * qmpc_command: everything ConvexMPCLocomotion::updateMPCIfNeeded
+ * (src/MPC_Ctrl/ConvexMPCLocomotion.cpp:498-577) and ::solveDenseMPC
+ * (:592-640) read from the state estimate and from the controller's members.
+ */
+typedef struct {
+  /* StateEstimate (seResult, :502 / :594) */
+  const float* position;    /* [B][3] */
+  const float* v_world;     /* [B][3] */
+  const float* omega_world; /* [B][3] */
+  const float* orientation; /* [B][4] w,x,y,z */
+  const float* rpy;         /* [B][3] */
+  const float* r_body;      /* [B][9] rBody, row-major */
+  const float* p_foot;      /* [B][12] pFoot[leg][axis] (world): p_foot[3*leg + axis] */
+  /* controller members */
+  const float* vel_des;      /* [B][3] _x_vel_des, _y_vel_des, _yaw_turn_rate */
+  const float* yaw_des_true; /* [B] */
+  const float* rpy_comp;     /* [B][2] */
+  const float* stand_traj;   /* [B][6]; may be NULL when no robot stands */
+  const float* rp_des;       /* [B][2] _roll_des, _pitch_des; NULL = zeros */
+  const int32_t* gait_type;  /* [B] current_gait, 4 = standing (:514); NULL = none stands */
+  const int32_t* gait_offsets;   /* [B][4] OffsetDurationGait::_offsets   (MPC segments) */
+  const int32_t* gait_durations; /* [B][4] OffsetDurationGait::_durations */
+  const int32_t* gait_iteration; /* [B]    OffsetDurationGait::_iteration (Gait.cpp:189) */
+  float* world_position_desired; /* [B][2] in/out (:535-545) */
+  float* x_comp_integral;        /* [B]    in/out (:632-640) */
+  float body_height;             /* _body_height */
+  int omni_mode;                 /* omniMode (:507) */
+} qmpc_command;
+
+/* Writable view of the arrays qmpc_inputs points at (the update_data_t record). */
+typedef struct {
+  float* p;
+  float* v;
+  float* q;
+  float* w;
+  float* r;
+  float* yaw;
+  float* traj;
+  uint8_t* gait;
+  float* x_drag;  /* [B] */
+  float* weights; /* [B][12] or NULL (caller keeps its own) */
+  float* alpha;   /* [B]     or NULL */
+} qmpc_record;
+
+/* Build the MPC input record of `batch` robots on the GPU: reference
+ * trajectory trajAll and the desired-position clamp (:534-576), standing
+ * trajectory (:514-531), r = pFoot - position (:611-613), yaw, Q and alpha
+ * (:598-604), x_drag = x_comp_integral followed by its integrator step
+ * (:632-640), and the contact table of OffsetDurationGait::getMpcTable
+ * (src/MPC_Ctrl/Gait.cpp:142-166) with n_segments = horizon.  dtMPC is the dt
+ * given to qmpc_setup.  Enqueues on `stream`; feed `rec`'s arrays to
+ * qmpc_solve through a qmpc_inputs with strides 12 / 1 / 1. */
+int qmpc_pack(qmpc_handle h, int batch, const qmpc_command* cmd,
+              const qmpc_record* rec, void* stream);
+
+/* f_ff[B][12]: f_ff[3*leg + i] = (-rBody * f_leg)[i] with f_leg = grf[3*leg..]
+ * (ConvexMPCLocomotion.cpp:672-680, the consumer of get_solution). */
+int qmpc_forces_to_body(qmpc_handle h, int batch, const float* r_body,
+                        const float* grf, float* f_ff, void* stream);
+
 /* Last HIP error string for this handle ("" if none). */
 const char* qmpc_last_error(qmpc_handle h);
 

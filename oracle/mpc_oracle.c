@@ -389,3 +389,108 @@ void oracle_mpc_table(int n_segments, const int offsets[4],
     }
   }
 }
+
+/* ------------------------------------------------------------------------
+ * Caller side: ConvexMPCLocomotion.cpp:498-577 (updateMPCIfNeeded) and
+ * :592-665 (solveDenseMPC), Gait.cpp:142-166.
+ */
+void oracle_pack_command(const oracle_command_t* c, float dt_mpc, int horizon,
+                         float wpd[2], float* xci, oracle_update_t* u) {
+  const float* p = c->position; /* :503 */
+  float traj_init[12];
+  int k, j;
+  /* :505-507  v_des_world = omniMode ? v_des_robot : rBody^T * v_des_robot */
+  const float vr[3] = {c->vel_des[0], c->vel_des[1], 0.f};
+  float vw[3];
+  if (c->omni_mode) {
+    vw[0] = vr[0];
+    vw[1] = vr[1];
+    vw[2] = vr[2];
+  } else {
+    for (k = 0; k < 3; k++) /* (R^T)(k,:) . v, accumulated left to right */
+      vw[k] = (c->r_body[0 * 3 + k] * vr[0] + c->r_body[1 * 3 + k] * vr[1]) +
+              c->r_body[2 * 3 + k] * vr[2];
+  }
+  if (c->gait_type == 4) { /* :514-531 */
+    const float t0[12] = {c->rp_des[0], c->rp_des[1], c->stand_traj[5],
+                          c->stand_traj[0], c->stand_traj[1], c->body_height,
+                          0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (k = 0; k < horizon; k++)
+      for (j = 0; j < 12; j++) u->traj[12 * k + j] = t0[j];
+  } else { /* :534-576 */
+    const float max_pos_error = .1f;
+    float x_start = wpd[0], y_start = wpd[1];
+    /* "p[0] + 0.1": double literal, result stored to float */
+    if (x_start - p[0] > max_pos_error) x_start = (float)((double)p[0] + 0.1);
+    if (p[0] - x_start > max_pos_error) x_start = (float)((double)p[0] - 0.1);
+    if (y_start - p[1] > max_pos_error) y_start = (float)((double)p[1] + 0.1);
+    if (p[1] - y_start > max_pos_error) y_start = (float)((double)p[1] - 0.1);
+    wpd[0] = x_start;
+    wpd[1] = y_start;
+    traj_init[0] = c->rpy_comp[0];
+    traj_init[1] = c->rpy_comp[1];
+    traj_init[2] = c->yaw_des_true;
+    traj_init[3] = x_start;
+    traj_init[4] = y_start;
+    traj_init[5] = c->body_height;
+    traj_init[6] = 0.f;
+    traj_init[7] = 0.f;
+    traj_init[8] = c->vel_des[2];
+    traj_init[9] = vw[0];
+    traj_init[10] = vw[1];
+    traj_init[11] = 0.f;
+    for (k = 0; k < horizon; k++) {
+      for (j = 0; j < 12; j++) u->traj[12 * k + j] = traj_init[j];
+      if (k == 0) {
+        u->traj[2] = c->yaw_des_true;
+      } else { /* :566-573 */
+        u->traj[12 * k + 3] = u->traj[12 * (k - 1) + 3] + dt_mpc * vw[0];
+        u->traj[12 * k + 4] = u->traj[12 * (k - 1) + 4] + dt_mpc * vw[1];
+        u->traj[12 * k + 2] = u->traj[12 * (k - 1) + 2] + dt_mpc * c->vel_des[2];
+      }
+    }
+  }
+  /* solveDenseMPC :598-613 */
+  {
+    static const float Q[12] = {2.5f, 2.5f, 10.f, 50.f, 50.f, 100.f,
+                                0.f,  0.f,  0.5f, 0.2f, 0.2f, 0.1f};
+    for (j = 0; j < 12; j++) u->weights[j] = Q[j];
+    u->alpha = 4e-5f; /* :604 */
+    u->yaw = c->rpy[2]; /* :602 */
+    for (j = 0; j < 3; j++) {
+      u->p[j] = c->position[j];
+      u->v[j] = c->v_world[j];
+      u->w[j] = c->omega_world[j];
+    }
+    for (j = 0; j < 4; j++) u->q[j] = c->orientation[j];
+    for (j = 0; j < 12; j++) /* :611-613  r[i] = pFoot[i%4][i/4] - position[i/4] */
+      u->r[j] = c->p_foot[3 * (j % 4) + j / 4] - c->position[j / 4];
+  }
+  /* :632 update_x_drag(x_comp_integral) comes BEFORE the integrator step :636-640 */
+  u->x_drag = *xci;
+  {
+    const float pz_err = p[2] - c->body_height; /* :625 */
+    const float vx = c->v_world[0];
+    const float cmpc_x_drag = 3.0f;
+    if ((double)vx > 0.3 || (double)vx < -0.3)
+      *xci += cmpc_x_drag * pz_err * dt_mpc / vx;
+  }
+  /* contact table, Gait.cpp:142-166 with _nIterations = horizon */
+  {
+    int table[4 * ORACLE_MAX_HORIZON];
+    oracle_mpc_table(horizon, c->gait_offsets, c->gait_durations, c->gait_iteration, table);
+    for (j = 0; j < 4 * horizon; j++) u->gait[j] = (unsigned char)table[j];
+  }
+}
+
+/* ConvexMPCLocomotion.cpp:672-680 */
+void oracle_forces_to_body(const float r_body[9], const float f_world[12],
+                           float f_ff[12]) {
+  int leg, i;
+  for (leg = 0; leg < 4; leg++) {
+    const float* f = &f_world[3 * leg];
+    for (i = 0; i < 3; i++) /* (-rBody)(i,:) . f, accumulated left to right */
+      f_ff[3 * leg + i] = ((-r_body[3 * i + 0]) * f[0] + (-r_body[3 * i + 1]) * f[1]) +
+                          (-r_body[3 * i + 2]) * f[2];
+  }
+}

@@ -108,6 +108,46 @@ int oracle_solve_mpc_batch(const oracle_update_t* u, int count,
 void oracle_mpc_table(int n_segments, const int offsets[4],
                       const int durations[4], int iteration, int* table);
 
+/* ------------------------------------------------------------------------
+ * Caller side of the solve (SURVEY.md row a12 / a11's consumer): what
+ * ConvexMPCLocomotion::updateMPCIfNeeded (ConvexMPCLocomotion.cpp:498-577) and
+ * ::solveDenseMPC (:592-665) compute around update_problem_data_floats.
+ * PARITY UNPINNED like the assembly (these members need Eigen to compile);
+ * plain float arithmetic restated operation by operation.
+ */
+typedef struct {
+  /* StateEstimate seResult (read at :502, :594) */
+  float position[3];
+  float v_world[3];
+  float omega_world[3];
+  float orientation[4]; /* w,x,y,z */
+  float rpy[3];
+  float r_body[9];  /* rBody, row-major */
+  float p_foot[12]; /* pFoot[leg][axis] (world), p_foot[3*leg + axis], :161 of the header */
+  /* controller members */
+  float vel_des[3]; /* _x_vel_des, _y_vel_des, _yaw_turn_rate */
+  float yaw_des_true;
+  float rpy_comp[2];
+  float stand_traj[6];
+  float rp_des[2]; /* _roll_des, _pitch_des */
+  int gait_type;   /* current_gait; 4 = standing (:514) */
+  int gait_offsets[4], gait_durations[4], gait_iteration;
+  float body_height;
+  int omni_mode;
+} oracle_command_t;
+
+/* updateMPCIfNeeded :498-577 (trajAll, world_position_desired clamp) +
+ * solveDenseMPC :598-640 (Q, alpha, r, yaw, x_drag = x_comp_integral BEFORE
+ * its update :632-640) + Gait.cpp:142-166 (contact table, n_segments =
+ * horizon).  wpd[2] = world_position_desired x,y (in/out), xci =
+ * x_comp_integral (in/out).  dt_mpc = float(dt * iterationsBetweenMPC). */
+void oracle_pack_command(const oracle_command_t* c, float dt_mpc, int horizon,
+                         float wpd[2], float* xci, oracle_update_t* u);
+
+/* ConvexMPCLocomotion.cpp:672-680: f_ff[leg] = -rBody * f, f = float(q_soln[3 leg + axis]). */
+void oracle_forces_to_body(const float r_body[9], const float f_world[12],
+                           float f_ff[12]);
+
 #ifdef __cplusplus
 }
 #endif

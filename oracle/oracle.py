@@ -211,3 +211,67 @@ def mpc_table(n_segments, offsets, durations, iteration):
     lib().oracle_mpc_table(n_segments, (C.c_int * 4)(*offsets),
                            (C.c_int * 4)(*durations), int(iteration), t)
     return np.array(t[:], np.int32)
+
+
+class CommandT(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("v_world", C.c_float * 3), ("omega_world", C.c_float * 3),
+                ("orientation", C.c_float * 4), ("rpy", C.c_float * 3), ("r_body", C.c_float * 9),
+                ("p_foot", C.c_float * 12), ("vel_des", C.c_float * 3), ("yaw_des_true", C.c_float),
+                ("rpy_comp", C.c_float * 2), ("stand_traj", C.c_float * 6), ("rp_des", C.c_float * 2),
+                ("gait_type", C.c_int), ("gait_offsets", C.c_int * 4), ("gait_durations", C.c_int * 4),
+                ("gait_iteration", C.c_int), ("body_height", C.c_float), ("omni_mode", C.c_int)]
+
+
+def pack_commands(cmd, dt_mpc):
+    """oracle_pack_command over a workloads.make_commands dict.  Returns the
+    record as a batch dict (workloads layout) plus the updated controller state."""
+    L = lib()
+    L.oracle_pack_command.argtypes = [C.POINTER(CommandT), C.c_float, C.c_int, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.POINTER(Update)]
+    L.oracle_pack_command.restype = None
+    B, h = int(cmd["batch"]), int(cmd["horizon"])
+    out = {k: np.zeros(s_, np.float32) for k, s_ in
+           (("p", (B, 3)), ("v", (B, 3)), ("q", (B, 4)), ("w", (B, 3)), ("r", (B, 12)), ("yaw", (B,)),
+            ("traj", (B, 12 * h)), ("weights", (B, 12)), ("alpha", (B,)), ("x_drag", (B,)))}
+    out["gait"] = np.zeros((B, 4 * h), np.uint8)
+    wpd = np.array(cmd["world_position_desired"], np.float32).copy()
+    xci = np.array(cmd["x_comp_integral"], np.float32).copy()
+    for i in range(B):
+        c = CommandT()
+        for k in ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot", "vel_des",
+                  "rpy_comp", "stand_traj", "rp_des"):
+            arr = np.asarray(cmd[k][i], np.float32).reshape(-1)
+            getattr(c, k)[:] = arr.tolist()
+        c.yaw_des_true = float(cmd["yaw_des_true"][i])
+        c.gait_type = int(cmd["gait_type"][i])
+        c.gait_offsets[:] = [int(x) for x in cmd["gait_offsets"][i]]
+        c.gait_durations[:] = [int(x) for x in cmd["gait_durations"][i]]
+        c.gait_iteration = int(cmd["gait_iteration"][i])
+        c.body_height = float(np.float32(cmd["body_height"]))
+        c.omni_mode = int(cmd["omni_mode"])
+        w2 = (C.c_float * 2)(*wpd[i].tolist())
+        x1 = C.c_float(float(xci[i]))
+        u = Update()
+        L.oracle_pack_command(C.byref(c), C.c_float(dt_mpc), h, w2, C.byref(x1), C.byref(u))
+        wpd[i] = [w2[0], w2[1]]
+        xci[i] = x1.value
+        for k in ("p", "v", "q", "w", "r", "weights"):
+            out[k][i] = np.frombuffer(getattr(u, k), np.float32)
+        out["yaw"][i], out["alpha"][i], out["x_drag"][i] = u.yaw, u.alpha, u.x_drag
+        out["traj"][i] = np.frombuffer(u.traj, np.float32)[:12 * h]
+        out["gait"][i] = np.frombuffer(u.gait, np.uint8)[:4 * h]
+    out["batch"], out["horizon"] = B, h
+    return out, wpd, xci
+
+
+def forces_to_body(r_body, grf):
+    L = lib()
+    L.oracle_forces_to_body.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.oracle_forces_to_body.restype = None
+    r_body = np.ascontiguousarray(r_body, np.float32)
+    grf = np.ascontiguousarray(grf, np.float32)
+    out = np.zeros_like(grf)
+    fp = C.POINTER(C.c_float)
+    for i in range(grf.shape[0]):
+        L.oracle_forces_to_body(r_body[i].ctypes.data_as(fp), grf[i].ctypes.data_as(fp), out[i].ctypes.data_as(fp))
+    return out

@@ -18,7 +18,15 @@ ST_ERROR_MASK = 15
 EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
-           "qmpc_set_debug_clock", "qmpc_set_max_stance"]
+           "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
+           "qmpc_forces_to_body"]
+
+# qmpc_command fields (include/qmpc.h), in declaration order
+CMD_F32 = ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot",
+           "vel_des", "yaw_des_true", "rpy_comp", "stand_traj", "rp_des")
+CMD_I32 = ("gait_type", "gait_offsets", "gait_durations", "gait_iteration")
+CMD_STATE = ("world_position_desired", "x_comp_integral")
+REC_FIELDS = ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "x_drag", "weights", "alpha")
 
 
 class Inputs(C.Structure):
@@ -32,6 +40,15 @@ class Inputs(C.Structure):
 class Outputs(C.Structure):
     _fields_ = [("grf", C.c_void_p), ("soln", C.c_void_p),
                 ("status", C.c_void_p), ("iters", C.c_void_p)]
+
+
+class Command(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in CMD_F32 + CMD_I32 + CMD_STATE] + [
+        ("body_height", C.c_float), ("omni_mode", C.c_int)]
+
+
+class Record(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in REC_FIELDS]
 
 
 _lib = None
@@ -62,6 +79,8 @@ def load_library():
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_pack.argtypes = [C.c_void_p, C.c_int, C.POINTER(Command), C.POINTER(Record), C.c_void_p]
+        lib.qmpc_forces_to_body.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -178,6 +197,48 @@ class BatchedConvexMPC:
         if full:
             res["soln"] = o["soln"].cpu().numpy()
         return res
+
+    # ---- caller side on the GPU (ConvexMPCLocomotion.cpp:498-640, :672-680) --
+    def upload_command(self, cmd):
+        """numpy command dict (workloads.make_commands layout) -> device tensors."""
+        t = self.torch
+        d = {}
+        for k in CMD_F32 + CMD_STATE:
+            d[k] = None if cmd.get(k) is None else t.from_numpy(np.ascontiguousarray(cmd[k], np.float32)).to(self.device)
+        for k in CMD_I32:
+            d[k] = None if cmd.get(k) is None else t.from_numpy(np.ascontiguousarray(cmd[k], np.int32)).to(self.device)
+        d["body_height"] = float(cmd["body_height"])
+        d["omni_mode"] = int(cmd["omni_mode"])
+        d["batch"] = int(cmd["batch"])
+        return d
+
+    def alloc_record(self, batch):
+        """Device arrays of the update_data_t record for `batch` robots."""
+        t, h = self.torch, self.horizon
+        f = lambda *shape: t.empty(shape, dtype=t.float32, device=self.device)
+        return {"p": f(batch, 3), "v": f(batch, 3), "q": f(batch, 4), "w": f(batch, 3), "r": f(batch, 12),
+                "yaw": f(batch), "traj": f(batch, 12 * h),
+                "gait": t.empty((batch, 4 * h), dtype=t.uint8, device=self.device),
+                "x_drag": f(batch), "weights": f(batch, 12), "alpha": f(batch), "batch": batch}
+
+    def pack_async(self, dcmd, rec, stream=None):
+        """Enqueue the record build (qmpc_pack) for the uploaded command."""
+        cs = Command()
+        for k in CMD_F32 + CMD_I32 + CMD_STATE:
+            setattr(cs, k, None if dcmd[k] is None else dcmd[k].data_ptr())
+        cs.body_height = dcmd["body_height"]
+        cs.omni_mode = dcmd["omni_mode"]
+        rs = Record()
+        for k in REC_FIELDS:
+            setattr(rs, k, rec[k].data_ptr())
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        self._check(self.lib.qmpc_pack(self.h, dcmd["batch"], C.byref(cs), C.byref(rs),
+                                       C.c_void_p(s.cuda_stream)), "qmpc_pack")
+
+    def forces_to_body_async(self, batch, r_body, grf, f_ff, stream=None):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        self._check(self.lib.qmpc_forces_to_body(self.h, batch, r_body.data_ptr(), grf.data_ptr(), f_ff.data_ptr(),
+                                                 C.c_void_p(s.cuda_stream)), "qmpc_forces_to_body")
 
     # ---- host-pointer path (what the single-robot shim uses) -------------
     def solve_host(self, b, full=False):

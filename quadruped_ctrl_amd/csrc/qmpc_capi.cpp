@@ -17,6 +17,9 @@
 
 extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
 extern "C" hipError_t qmpc_prepare(void);
+extern "C" hipError_t qmpc_launch_pack(const qmpc_command* c, const qmpc_record* rec, int batch, int horizon, float dt_mpc,
+                                       hipStream_t stream);
+extern "C" hipError_t qmpc_launch_f2b(const float* r_body, const float* grf, float* f_ff, int batch, hipStream_t stream);
 
 struct qmpc_ctx {
   int device = 0;
@@ -69,7 +72,7 @@ int fail(qmpc_ctx* c, hipError_t e, const char* what) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 1; }
+int qmpc_abi_version(void) { return 2; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -262,6 +265,32 @@ int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outpu
     P.next_list = nullptr; P.next_count = nullptr;
     HIP_TRY(c, qmpc_launch(3, &P, batch, stream));
   }
+  return QMPC_OK;
+}
+
+int qmpc_pack(qmpc_handle c, int batch, const qmpc_command* cmd, const qmpc_record* rec, void* stream_) {
+  if (!c || !cmd || !rec) return QMPC_ERR_ARG;
+  if (!c->is_setup) return QMPC_ERR_STATE;
+  if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  if (!cmd->position || !cmd->v_world || !cmd->omega_world || !cmd->orientation || !cmd->rpy || !cmd->r_body ||
+      !cmd->p_foot || !cmd->vel_des || !cmd->yaw_des_true || !cmd->rpy_comp || !cmd->gait_offsets ||
+      !cmd->gait_durations || !cmd->gait_iteration || !cmd->world_position_desired || !cmd->x_comp_integral)
+    return QMPC_ERR_ARG;
+  if (cmd->gait_type && !cmd->stand_traj) return QMPC_ERR_ARG;  // a standing robot needs its stand_traj row
+  if (!rec->p || !rec->v || !rec->q || !rec->w || !rec->r || !rec->yaw || !rec->traj || !rec->gait || !rec->x_drag)
+    return QMPC_ERR_ARG;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, qmpc_launch_pack(cmd, rec, batch, c->horizon, (float)c->dt, (hipStream_t)stream_));
+  return QMPC_OK;
+}
+
+int qmpc_forces_to_body(qmpc_handle c, int batch, const float* r_body, const float* grf, float* f_ff, void* stream_) {
+  if (!c || !r_body || !grf || !f_ff) return QMPC_ERR_ARG;
+  if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, qmpc_launch_f2b(r_body, grf, f_ff, batch, (hipStream_t)stream_));
   return QMPC_OK;
 }
 

@@ -134,3 +134,62 @@ def shard(d, rank, world):
            for k, v in d.items()}
     out["batch"] = hi - lo
     return out
+
+
+def make_commands(batch, horizon=10, seed=7, stand_fraction=0.1, omni_mode=0, calm=False):
+    """Synthetic controller commands + estimator states for the caller-side
+    packer (include/qmpc.h qmpc_command; ConvexMPCLocomotion.cpp:498-640).
+    Gaits: the h-segment rescalings of trot / bounding / pacing used by
+    make_config; `stand_fraction` of the robots are in current_gait == 4.
+    calm=True: small commands that the robot already tracks (few active
+    constraints, like configs[1]); default: aggressive commands and up to 0.25 m
+    of position error (many active constraints, exercises every clamp branch)."""
+    rng = np.random.default_rng(seed)
+    B, h = batch, horizon
+    f32 = np.float32
+    rpy = rng.normal(0, 0.05, (B, 3)).astype(f32)
+    rpy[:, 2] = rng.uniform(-3.0, 3.0, B)
+    quat = _quat_from_rpy(rpy.astype(np.float64)).astype(f32)
+    cy, sy = np.cos(rpy[:, 2].astype(np.float64)), np.sin(rpy[:, 2].astype(np.float64))
+    r_body = np.zeros((B, 3, 3))
+    r_body[:, 0, 0], r_body[:, 0, 1] = cy, sy        # world -> body for a yaw-only attitude
+    r_body[:, 1, 0], r_body[:, 1, 1] = -sy, cy
+    r_body[:, 2, 2] = 1.0
+    pos = (np.array([0, 0, 0.29]) + rng.normal(0, [0.5, 0.5, 0.01], (B, 3))).astype(f32)
+    hip = np.array([[.19, -.111, -.29], [.19, .111, -.29], [-.19, -.111, -.29], [-.19, .111, -.29]])
+    # feet under the hips of the yawed body (body -> world = rBody^T), 2 cm of scatter
+    hip_w = np.einsum("bji,lj->bli", r_body, hip)
+    p_foot = (pos[:, None, :].astype(np.float64) + hip_w + rng.normal(0, 0.02, (B, 4, 3))).astype(f32)
+    amp = 0.3 if calm else 1.0
+    vel_des = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B), rng.uniform(-1, 1, B)], 1) * amp
+    v_des_w = np.einsum("bji,bj->bi", r_body, np.concatenate([vel_des[:, :2], np.zeros((B, 1))], 1))
+    gaits = {"trot": ((0, h // 2, h // 2, 0), (h // 2,) * 4),
+             "bound": ((h // 2, h // 2, 0, 0), (max(h // 2 - 1, 1),) * 4),
+             "pace": ((h // 2, 0, h // 2, 0), (h // 2,) * 4),
+             "stand": ((0, 0, 0, 0), (h,) * 4)}
+    names = rng.choice(["trot", "bound", "pace"], B)
+    stand = rng.random(B) < stand_fraction
+    names = np.where(stand, "stand", names)
+    cmd = {
+        "batch": B, "horizon": h,
+        "position": pos,
+        "v_world": (v_des_w + rng.normal(0, 0.02 if calm else 0.1, (B, 3))).astype(f32),   # tracking the command
+        "omega_world": (rng.normal(0, 0.2, (B, 3)) * (0.2 if calm else 1.0)).astype(f32),
+        "orientation": quat, "rpy": rpy,
+        "r_body": r_body.reshape(B, 9).astype(f32),
+        "p_foot": p_foot.reshape(B, 12),
+        "vel_des": vel_des.astype(f32),
+        "yaw_des_true": (rpy[:, 2] + rng.normal(0, 0.05, B)).astype(f32),
+        "rpy_comp": rng.normal(0, 0.02, (B, 2)).astype(f32),
+        "stand_traj": np.concatenate([pos, rpy], 1).astype(f32),
+        "rp_des": rng.normal(0, 0.01, (B, 2)).astype(f32),
+        "gait_type": np.where(stand, 4, 0).astype(np.int32),
+        "gait_offsets": np.array([gaits[n][0] for n in names], np.int32),
+        "gait_durations": np.array([gaits[n][1] for n in names], np.int32),
+        "gait_iteration": rng.integers(0, h, B).astype(np.int32),
+        # desired position up to 0.25 m away from the estimate: exercises all four clamp branches
+        "world_position_desired": (pos[:, :2] + rng.uniform(-0.25, 0.25, (B, 2)) * (0.05 if calm else 1.0)).astype(f32),
+        "x_comp_integral": rng.normal(0, 0.01, B).astype(f32),
+        "body_height": 0.29, "omni_mode": int(omni_mode),
+    }
+    return cmd

@@ -23,7 +23,8 @@ from oracle import oracle as O
 from quadruped_ctrl_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+              if not os.path.basename(p).startswith("pack_"))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -310,3 +311,84 @@ def test_many_active_constraints_engine_fallback(mpc_factory):
     assert worst < 1e-7
     assert res["iters"].max() > 30            # a genuinely large working set
     assert (res["status"] & 16).any()         # ... that exercised the fallback engine
+
+
+# ---------------------------------------------------------------- caller side on the GPU
+REC_KEYS = ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights", "alpha", "x_drag")
+
+
+def _gpu_pack(m, cmd):
+    import torch
+    dcmd = m.upload_command(cmd)
+    rec = m.alloc_record(cmd["batch"])
+    m.pack_async(dcmd, rec)
+    torch.cuda.synchronize()
+    got = {k: rec[k].cpu().numpy() for k in REC_KEYS}
+    return got, dcmd["world_position_desired"].cpu().numpy(), dcmd["x_comp_integral"].cpu().numpy(), rec
+
+
+def _pack_setup(cmd, dt=0.026):
+    return {"batch": cmd["batch"], "horizon": cmd["horizon"], "dt": dt, "mu": 0.4, "f_max": 120.0}
+
+
+@pytest.mark.parametrize("name", ["pack_h10", "pack_h16_omni"])
+def test_pack_golden_bit_exact(name, mpc_factory):
+    """qmpc_pack / qmpc_forces_to_body against the committed fixtures: float and
+    integer work, so the bar is bit-exact."""
+    import torch
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    cmd = {k[4:]: z[k] for k in z.files if k.startswith("cmd_")}
+    for k in ("batch", "horizon", "omni_mode"):
+        cmd[k] = int(cmd[k])
+    cmd["body_height"] = float(cmd["body_height"])
+    m = mpc_factory(_pack_setup(cmd, float(z["dt"])))
+    got, wpd, xci, _ = _gpu_pack(m, cmd)
+    for k in REC_KEYS:
+        assert np.array_equal(got[k], z["rec_" + k]), k
+    assert np.array_equal(wpd, z["wpd_out"]) and np.array_equal(xci, z["xci_out"])
+    rb = torch.from_numpy(cmd["r_body"]).cuda()
+    grf = torch.from_numpy(z["grf"]).cuda()
+    f_ff = torch.empty_like(grf)
+    m.forces_to_body_async(cmd["batch"], rb, grf, f_ff)
+    torch.cuda.synchronize()
+    assert np.array_equal(f_ff.cpu().numpy(), z["f_ff"])
+
+
+@pytest.mark.parametrize("B,h,omni", [(1, 10, 0), (3, 12, 1), (1025, 10, 0), (260, 16, 0)])
+def test_pack_vs_live_oracle_ragged_batches(B, h, omni, mpc_factory):
+    cmd = W.make_commands(B, horizon=h, seed=100 + B, omni_mode=omni, stand_fraction=0.2)
+    m = mpc_factory(_pack_setup(cmd))
+    got, wpd, xci, _ = _gpu_pack(m, cmd)
+    ref, wpd_r, xci_r = O.pack_commands(cmd, np.float32(0.026))
+    for k in REC_KEYS:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(wpd, wpd_r) and np.array_equal(xci, xci_r)
+
+
+def test_pack_then_solve_end_to_end(mpc_factory):
+    """command -> record -> solve -> body-frame forces entirely on the GPU, against
+    the reference pipeline (oracle packing + oracle assembly + reference qpOASES)."""
+    import torch
+    cmd = W.make_commands(192, horizon=10, seed=77, stand_fraction=0.15)
+    m = mpc_factory(_pack_setup(cmd))
+    dcmd = m.upload_command(cmd)
+    rec = m.alloc_record(cmd["batch"])
+    o = m.alloc_outputs(cmd["batch"], full=True)
+    inp, out = m.make_args(rec, o)
+    m.pack_async(dcmd, rec)
+    m.solve_async(cmd["batch"], inp, out)           # same stream: ordered after the pack
+    f_ff = torch.empty_like(o["grf"])
+    m.forces_to_body_async(cmd["batch"], dcmd["r_body"], o["grf"], f_ff)
+    torch.cuda.synchronize()
+    assert ((o["status"].cpu().numpy() & 15) == 0).all()
+    ref_rec, _, _ = O.pack_commands(cmd, np.float32(0.026))
+    ref_rec.update(dt=0.026, mu=0.4, f_max=120.0)
+    q, nwsr, rc = O.solve_batch(ref_rec)
+    assert (rc == 0).all()
+    grf = o["grf"].cpu().numpy()
+    assert rel_f0(grf, q).max() < 1e-4
+    # the rotation is exact given the forces
+    assert np.array_equal(f_ff.cpu().numpy(), O.forces_to_body(cmd["r_body"], grf))
+    # and the packed record gives the same answer as the same record uploaded from the host
+    res = m.solve(ref_rec)
+    assert np.array_equal(res["grf"], grf)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(binding.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qmpc_abi_version() == 1
+    assert lib.qmpc_abi_version() == 2
 
 
 def test_shim_exports_reference_symbols():
@@ -98,3 +98,73 @@ def test_shard_is_disjoint_cover():
     assert sum(p["batch"] for p in parts) == 37
     assert np.array_equal(np.concatenate([p["p"] for p in parts]), b["p"])
     assert np.array_equal(np.concatenate([p["gait"] for p in parts]), b["gait"])
+
+
+# ---------------------------------------------------------------- caller-side packer
+def _load_pack_golden(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    cmd = {k[4:]: z[k] for k in z.files if k.startswith("cmd_")}
+    for k in ("batch", "horizon", "omni_mode"):
+        cmd[k] = int(cmd[k])
+    cmd["body_height"] = float(cmd["body_height"])
+    rec = {k[4:]: z[k] for k in z.files if k.startswith("rec_")}
+    return z, cmd, rec
+
+
+@pytest.mark.parametrize("name", ["pack_h10", "pack_h16_omni"])
+def test_oracle_pack_matches_golden(name):
+    z, cmd, rec = _load_pack_golden(name)
+    got, wpd, xci = O.pack_commands(cmd, np.float32(z["dt"]))
+    for k, v in rec.items():
+        assert np.array_equal(got[k], v), k            # float code restated op by op: bit exact
+    assert np.array_equal(wpd, z["wpd_out"]) and np.array_equal(xci, z["xci_out"])
+    assert np.array_equal(O.forces_to_body(cmd["r_body"], z["grf"]), z["f_ff"])
+
+
+def test_oracle_pack_properties():
+    """What ConvexMPCLocomotion.cpp:498-640 guarantees, checked on the restatement."""
+    h = 10
+    cmd = W.make_commands(256, horizon=h, seed=21)
+    dt = np.float32(0.026)
+    rec, wpd, xci = O.pack_commands(cmd, dt)
+    tr = rec["traj"].reshape(-1, h, 12)
+    stand = cmd["gait_type"] == 4
+    assert stand.any() and (~stand).any()
+    # standing: every row is the same trajInitial (:514-531)
+    assert (tr[stand] == tr[stand][:, :1]).all()
+    assert np.array_equal(tr[stand][:, 0, 3:5], cmd["stand_traj"][stand][:, 0:2])
+    assert np.array_equal(wpd[stand], cmd["world_position_desired"][stand])     # untouched
+    mv = ~stand
+    # moving: rows other than yaw/x/y are constant; x,y,yaw are running float sums (:566-573)
+    for j in (0, 1, 5, 6, 7, 8, 9, 10, 11):
+        assert (tr[mv][:, :, j] == tr[mv][:, :1, j]).all(), j
+    vw = tr[mv][:, 0, 9:11]
+    for k in range(1, h):
+        assert np.array_equal(tr[mv][:, k, 3], tr[mv][:, k - 1, 3] + dt * vw[:, 0])
+        assert np.array_equal(tr[mv][:, k, 2], tr[mv][:, k - 1, 2] + dt * cmd["vel_des"][mv][:, 2])
+    # the desired position is pulled to within 0.1 m of the estimate (:534-545)
+    assert (np.abs(wpd[mv] - cmd["position"][mv][:, :2]) <= 0.1 + 1e-6).all()
+    assert (np.abs(cmd["world_position_desired"][mv] - cmd["position"][mv][:, :2]) > 0.1).any()
+    # v_des_world = rBody^T v_des_robot (:507): planar rotation by -yaw keeps the norm
+    assert np.allclose(np.linalg.norm(vw, axis=1), np.linalg.norm(cmd["vel_des"][mv][:, :2], axis=1), atol=1e-6)
+    # x_drag is the integral BEFORE its update; the update needs |vx| > 0.3 (:632-640)
+    assert np.array_equal(rec["x_drag"], cmd["x_comp_integral"])
+    moved = xci != cmd["x_comp_integral"]
+    assert moved.any() and (~moved).any()
+    assert (np.abs(cmd["v_world"][moved][:, 0]) > 0.3).all()
+    # foot offsets, axis-major (:611-613), and the contact table (Gait.cpp:142-166)
+    pf = cmd["p_foot"].reshape(-1, 4, 3)
+    assert np.array_equal(rec["r"].reshape(-1, 3, 4), np.transpose(pf - cmd["position"][:, None, :], (0, 2, 1)))
+    for i in range(0, 256, 17):
+        assert np.array_equal(rec["gait"][i], gait.mpc_table(h, cmd["gait_offsets"][i], cmd["gait_durations"][i],
+                                                             cmd["gait_iteration"][i]))
+    assert np.array_equal(rec["weights"][3], np.float32([2.5, 2.5, 10, 50, 50, 100, 0, 0, 0.5, 0.2, 0.2, 0.1]))
+    assert (rec["alpha"] == np.float32(4e-5)).all()
+
+
+def test_pack_argument_validation_without_gpu():
+    _build_once()
+    lib = binding.load_library()
+    cs, rs = binding.Command(), binding.Record()
+    assert lib.qmpc_pack(None, 4, C.byref(cs), C.byref(rs), None) == 1
+    assert lib.qmpc_forces_to_body(None, 4, None, None, None, None) == 1
