@@ -198,9 +198,10 @@ struct Cfg {
   static constexpr int NP = 64 * RB;
   static constexpr int CW = 16 * RB;
   static constexpr int NT = 256 * RB;
-  // working-set slots: every n_r <= 64 problem fits 64; the largest class is
-  // bounded by the 160 KiB of LDS next to its 148 KiB inverse
-  static constexpr int KMAX = (RB == 1) ? 64 : (RB == 2 ? 96 : 48);
+  // working-set slots: every n_r <= 64 problem fits 64; in the largest class the
+  // 160 KiB of LDS next to the packed inverse set the bound at run time (48 slots at
+  // n_r = 192, all 96 at n_r <= 168)
+  static constexpr int KMAX = (RB == 1) ? 64 : 96;
   static constexpr int KW = (KMAX + 63) / 64;  // slots per engine lane
   static constexpr int NS = KMAX * (KMAX + 1) / 2;
   static constexpr int NH = NP * (NP + 1) / 2;
@@ -208,8 +209,8 @@ struct Cfg {
   // one (z~, g~) record of NP + KS doubles per working-set change; Schur-form
   // engine: packed S_W^-1 (front) and rows H^-1 c_w (back).  Sized so that
   // class 1 keeps 4 workgroups per CU
-  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : NS);
-  static constexpr int NPOOL = POOL > NS ? POOL : NS;
+  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : 1176);
+  static constexpr int NPOOL = POOL;
   static constexpr int KS = (RB == 1) ? 32 : 64;  // event-form engine: working-set slot capacity (one per lane)
 };
 
@@ -817,7 +818,13 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  for (int k = tid; k < (V5 ? C::NPOOL : C::NS); k += NT) Sb.Sinv[k] = 0.0;  // V5: event rows start out zero
+  if constexpr (V5) {
+    for (int k = tid; k < C::NPOOL; k += NT) Sb.Sinv[k] = 0.0;  // event rows start out zero
+  } else {
+    // packed S_W^-1 behind the n(n+1)/2 doubles of the inverse (see stage 5)
+    const int nh0 = n * (n + 1) / 2, cap0 = C::NH + C::NPOOL - nh0;
+    for (int k = tid; k < (cap0 < C::NS ? cap0 : C::NS); k += NT) Sb.Hp[nh0 + k] = 0.0;
+  }
   if constexpr (V5) {
     // diagonal of H^-1: entry (i,i) is register i % CW of column group i / CW
     if (c == i / CW) {
@@ -1157,7 +1164,13 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
     };
     // row w of M = H^-1 C_W lives at the back of the pool while it does not collide with S_W^-1
-    auto m_row = [&](int w) __attribute__((always_inline)) { return &Sb.Sinv[C::NS - NP * (w + 1)]; };
+    // The packed inverse only occupies n(n+1)/2 doubles of Hp: the working-set storage
+    // starts right behind it, so a smaller problem gets room for more constraints
+    // (class 3: 48 slots at n = 192, 96 at n <= 168).
+    const int nh = n * (n + 1) / 2;
+    double* const swp = Sb.Hp + nh;                      // packed S_W^-1, growing from the front
+    const int cap = C::NH + C::NPOOL - nh;              // doubles available
+    auto m_row = [&](int w) __attribute__((always_inline)) { return swp + cap - NP * (w + 1); };
 
     unsigned amask = 0;  // stance-slot lane: bit ty = constraint (sl, ty) is in the working set
     int wcid[KW];        // working-slot lane: constraint id in slot w + 64 q, -1 = free
@@ -1247,7 +1260,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int v = v0 + u;
-              sv[q][u] = (w < khw && v < khw) ? Sb.Sinv[sym_idx(w, v)] : 0.0;
+              sv[q][u] = (w < khw && v < khw) ? swp[sym_idx(w, v)] : 0.0;
             }
           }
 #pragma unroll
@@ -1354,7 +1367,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
             const unsigned long long m = __ballot(fr);
             if (qslot < 0 && m) qslot = 64 * q + __ffsll((long long)m) - 1;
           }
-          if (qslot < 0) {
+          if (qslot < 0 || ((qslot + 1 > khw) ? (qslot + 1) * (qslot + 2) / 2 : 0) > cap) {
             status |= QMPC_DEV_ST_WS_FULL;
             done = true;
             break;
@@ -1363,7 +1376,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           // the packed S_W^-1 grows with the high-water mark: rows of M it would
           // overwrite are given up first
           {
-            const int room = (C::NS - kn * (kn + 1) / 2) / NP;  // rows of M that still fit behind it
+            const int room = (cap - kn * (kn + 1) / 2) / NP;  // rows of M that still fit behind it
             const int want = (qslot == mvalid) ? mvalid + 1 : mvalid;
             mvalid = want < room ? want : (mvalid < room ? mvalid : room);
             if (mvalid < 0) mvalid = 0;
@@ -1378,7 +1391,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const int hi = h0 + u, lo = lane + 64 * q;
-                old[q][u] = (hi < kn && lo <= hi) ? Sb.Sinv[hi * (hi + 1) / 2 + lo] : 0.0;
+                old[q][u] = (hi < kn && lo <= hi) ? swp[hi * (hi + 1) / 2 + lo] : 0.0;
               }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1393,7 +1406,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
                   else if (hi == qslot) v = -rw[q] * dinv;
                   else if (lo == qslot) v = -rhi * dinv;
                   else v = __builtin_fma(rhi * dinv, rw[q], old[q][u]);
-                  Sb.Sinv[hi * (hi + 1) / 2 + lo] = v;
+                  swp[hi * (hi + 1) / 2 + lo] = v;
                 }
               }
             }
@@ -1421,16 +1434,16 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         // partial step: the multiplier of slot l hit zero -> drop it.
         //   S' = S - S[:,l] S[l,:] / S[l,l] on the other slots; row/col l is
         //   only read here and zeroed afterwards, so in place is safe.
-        const double il = fast_rcp(Sb.Sinv[sym_idx(l, l)]);
+        const double il = fast_rcp(swp[sym_idx(l, l)]);
         for (int hi = 0; hi < khw; ++hi) {
           if (hi == l) continue;
-          const double shl = Sb.Sinv[sym_idx(hi, l)] * il;
+          const double shl = swp[sym_idx(hi, l)] * il;
 #pragma unroll
           for (int q = 0; q < KW; ++q) {
             const int lo = lane + 64 * q;
             if (lo <= hi && lo != l) {
               const int idx = hi * (hi + 1) / 2 + lo;
-              Sb.Sinv[idx] = __builtin_fma(-shl, Sb.Sinv[sym_idx(l, lo)], Sb.Sinv[idx]);
+              swp[idx] = __builtin_fma(-shl, swp[sym_idx(l, lo)], swp[idx]);
             }
           }
         }
@@ -1438,7 +1451,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
         for (int q = 0; q < KW; ++q) {
           const int w = lane + 64 * q;
-          if (w < khw) Sb.Sinv[sym_idx(w, l)] = 0.0;
+          if (w < khw) swp[sym_idx(w, l)] = 0.0;
         }
         // the dropped constraint leaves its slot: clear lane-w and lane-sl state
         const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, (l >> 6) < KW ? (l >> 6) : 0), l & 63);

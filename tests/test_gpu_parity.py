@@ -392,3 +392,29 @@ def test_pack_then_solve_end_to_end(mpc_factory):
     # and the packed record gives the same answer as the same record uploaded from the host
     res = m.solve(ref_rec)
     assert np.array_equal(res["grf"], grf)
+
+
+def test_class3_working_set_beyond_48_slots(mpc_factory):
+    """n_r = 168 (h = 14, all four feet down) with aggressive commands: more than 48
+    working constraints.  Class 3 places its working-set storage right behind the
+    packed inverse, so only n_r = 192 is limited to 48 slots."""
+    cmd = W.make_commands(150, horizon=14, seed=6, stand_fraction=0.1)
+    b, _, _ = O.pack_commands(cmd, np.float32(0.026))
+    b.update(dt=0.026, mu=0.4, f_max=120.0)
+    m = mpc_factory(b)
+    Hd, gd, ld = m.debug_dump(b["batch"])
+    res = m.solve(b, full=True)
+    m.debug_off()
+    Hd, gd = Hd.cpu().numpy(), gd.cpu().numpy()
+    assert ((res["status"] & 15) == 0).all()
+    nst = (b["gait"] != 0).sum(1)
+    big = np.nonzero((3 * nst > 128) & (res["iters"] > 48))[0]
+    assert len(big) >= 2
+    for i in big:
+        H, g, A, lb, ub, x0 = O.assemble(b, i)
+        ve, Hr, gr, Ar, lr, ur = O.reduce(H, g, A, lb, ub)
+        n = gr.size
+        xq, y, used, rc, irc = O.qpoases(Hd[i][:n, :n], gd[i][:n], Ar, lr, ur, nwsr=20000)
+        assert rc == 0 and irc == 0
+        xs = res["soln"][i][~ve]
+        assert np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0) < 1e-8
