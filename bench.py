@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index")
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (override)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream measurement")
     ap.add_argument("--caller-side", action="store_true",
                     help="time command -> record (qmpc_pack) -> solve -> body-frame forces per step instead of the "
                          "solve alone (SURVEY row a12 on the GPU; not the headline configuration)")
@@ -165,6 +166,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- extra (not part of the contract fields): the same K steps with two independent
+    # batches in flight on two HIP streams.  At batch 1024 a launch is exactly one round of
+    # workgroups and ends with its slowest robot (13 active-set iterations vs a median of 2),
+    # so back-to-back launches on ONE stream leave most of the GPU idle during every tail;
+    # a second stream lets the next batch start in the slots the early finishers free.
+    pipelined = None
+    if world == 1 and not args.caller_side and not args.no_pipelined:
+        streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        ctx = [(mpc, inp, out)]
+        mpc2 = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=16)
+        mpc2.setup(b["dt"], h, b["mu"], b["f_max"])
+        if not args.no_hint:
+            mpc2.set_max_stance(max_stance)
+        o2 = mpc2.alloc_outputs(per_gpu, full=False, iters=True)
+        inp2, out2 = mpc2.make_args(d, o2)            # same resident inputs, its own outputs
+        ctx.append((mpc2, inp2, out2))
+        for k in range(2 * max(args.warmup, 2)):
+            m_, i_, o_ = ctx[k % 2]
+            m_.solve_async(per_gpu, i_, o_, streams[k % 2])
+        torch.cuda.synchronize(dev)
+        tp = time.perf_counter()
+        for k in range(args.steps):
+            m_, i_, o_ = ctx[k % 2]
+            m_.solve_async(per_gpu, i_, o_, streams[k % 2])
+        torch.cuda.synchronize(dev)
+        tp = time.perf_counter() - tp
+        same = bool(torch.equal(o["grf"], o2["grf"]))
+        pipelined = {"streams": 2, "value": per_gpu * args.steps / tp, "unit": "QP solves/s",
+                     "ms_per_step": tp / args.steps * 1e3, "results_identical_to_single_stream": same,
+                     "note": "two independent batches in flight on two HIP streams (K steps total); the "
+                             "contract fields above are the single-stream run"}
+        mpc2.close()
+
     status = o["status"].cpu().numpy()
     iters = o["iters"].cpu().numpy()
     nst = ((rec["gait"].cpu().numpy() if args.caller_side else b["gait"]) != 0).sum(1)
@@ -214,6 +248,8 @@ def main():
                              "alg_bytes_per_qp": alg_bytes_per_qp(h),
                              "note": "728 B in + 48 B out per robot: tiny by construction"},
         }
+        if pipelined is not None:
+            res["pipelined"] = pipelined
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(b)
         print(json.dumps(res))
