@@ -83,9 +83,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (override)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream measurement")
-    ap.add_argument("--caller-side", action="store_true",
-                    help="time command -> record (qmpc_pack) -> solve -> body-frame forces per step instead of the "
-                         "solve alone (SURVEY row a12 on the GPU; not the headline configuration)")
+    ap.add_argument("--caller-side", choices=["fused", "three-calls"], default=None,
+                    help="time command -> record -> solve -> body-frame forces per step instead of the solve alone "
+                         "(SURVEY row a12 on the GPU; not the headline configuration): 'fused' = one "
+                         "qmpc_solve_commands launch, 'three-calls' = qmpc_pack + qmpc_solve + qmpc_forces_to_body")
     ap.add_argument("--no-hint", action="store_true",
                     help="do not tell the solver the workload's max stance foot-steps (launch every size class)")
     args = ap.parse_args()
@@ -137,10 +138,17 @@ def main():
             mpc.set_max_stance(max_stance)
         solve_only = mpc.solve_async
 
+        cs = mpc.make_command_args(dcmd)
+
         def step_all(n, inp_, out_, stream_):
-            mpc.pack_async(dcmd, rec, stream_)
-            solve_only(n, inp_, out_, stream_)
-            mpc.forces_to_body_async(n, dcmd["r_body"], o["grf"], f_ff, stream_)
+            if args.caller_side == "fused":
+                mpc.solve_commands_async(n, cs, out_, f_ff, stream_)
+            else:
+                mpc.pack_async(dcmd, rec, stream_)
+                solve_only(n, inp_, out_, stream_)
+                mpc.forces_to_body_async(n, dcmd["r_body"], o["grf"], f_ff, stream_)
+        if args.caller_side == "fused":   # the record is never materialised: build it once for the statistics below
+            mpc.pack_async(mpc.upload_command(cmd), rec, stream)
         mpc.solve_async = step_all
 
     def sync_all():
@@ -225,7 +233,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("caller-side pipeline (qmpc_pack + solve + forces_to_body), " if args.caller_side else "") +
+            "config": {"workload": (f"caller-side pipeline ({args.caller_side}: command -> record -> solve -> body-frame forces), " if args.caller_side else "") +
                                    f"BASELINE.json configs[{args.config}]: batch={per_gpu} robots/GPU, "
                                    f"horizon={h}, mean reduced QP size {3.0 * nst.mean():.1f} vars",
                        "batch_per_gpu": per_gpu, "horizon": h, "sharding": f"independent robots x{world}",
@@ -238,7 +246,7 @@ def main():
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (step_ms_ev * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "kernel": "qmpc_solve_kernel<1>", "kernel_ms_hip_events": step_ms_ev,
+                         "kernel": "qmpc_solve_kernel<1, false>", "kernel_ms_hip_events": step_ms_ev,
                          "alg_flops_per_qp": flops / per_gpu,
                          "note": "algorithmic fp64 flops F_alg(h, n_r, K) of SURVEY.md 8d over the HIP-event kernel "
                                  "time, against the dense fp64 peak (MFMA == vector rate on MI355X); traffic = "

@@ -206,6 +206,15 @@ int qmpc_pack(qmpc_handle h, int batch, const qmpc_command* cmd,
 int qmpc_forces_to_body(qmpc_handle h, int batch, const float* r_body,
                         const float* grf, float* f_ff, void* stream);
 
+/* The three calls above fused into ONE launch: the record is generated inside
+ * the solve kernel's first stage from `cmd` (never written to memory), the
+ * controller state in `cmd` is updated by the workgroup that solves the robot,
+ * and, when f_ff is non-NULL, the body-frame forces are written next to grf.
+ * Q and alpha are the reference's literals (:598, :604).  Results are
+ * bit-identical to qmpc_pack -> qmpc_solve -> qmpc_forces_to_body. */
+int qmpc_solve_commands(qmpc_handle h, int batch, const qmpc_command* cmd,
+                        const qmpc_outputs* out, float* f_ff, void* stream);
+
 /* Last HIP error string for this handle ("" if none). */
 const char* qmpc_last_error(qmpc_handle h);
 

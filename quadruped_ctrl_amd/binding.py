@@ -19,7 +19,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
-           "qmpc_forces_to_body"]
+           "qmpc_forces_to_body", "qmpc_solve_commands"]
 
 # qmpc_command fields (include/qmpc.h), in declaration order
 CMD_F32 = ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot",
@@ -80,6 +80,8 @@ def load_library():
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_pack.argtypes = [C.c_void_p, C.c_int, C.POINTER(Command), C.POINTER(Record), C.c_void_p]
+        lib.qmpc_solve_commands.argtypes = [C.c_void_p, C.c_int, C.POINTER(Command), C.POINTER(Outputs), C.c_void_p,
+                                            C.c_void_p]
         lib.qmpc_forces_to_body.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
@@ -234,6 +236,21 @@ class BatchedConvexMPC:
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         self._check(self.lib.qmpc_pack(self.h, dcmd["batch"], C.byref(cs), C.byref(rs),
                                        C.c_void_p(s.cuda_stream)), "qmpc_pack")
+
+    def make_command_args(self, dcmd):
+        cs = Command()
+        for k in CMD_F32 + CMD_I32 + CMD_STATE:
+            setattr(cs, k, None if dcmd[k] is None else dcmd[k].data_ptr())
+        cs.body_height = dcmd["body_height"]
+        cs.omni_mode = dcmd["omni_mode"]
+        return cs
+
+    def solve_commands_async(self, batch, cs, out, f_ff=None, stream=None):
+        """One fused launch: command -> (record in registers) -> solve -> grf (+ body-frame forces)."""
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        self._check(self.lib.qmpc_solve_commands(self.h, batch, C.byref(cs), C.byref(out),
+                                                 None if f_ff is None else f_ff.data_ptr(),
+                                                 C.c_void_p(s.cuda_stream)), "qmpc_solve_commands")
 
     def forces_to_body_async(self, batch, r_body, grf, f_ff, stream=None):
         s = stream if stream is not None else self.torch.cuda.current_stream(self.device)

@@ -72,7 +72,7 @@ int fail(qmpc_ctx* c, hipError_t e, const char* what) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 2; }
+int qmpc_abi_version(void) { return 3; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -187,29 +187,58 @@ int qmpc_set_debug_clock(qmpc_handle c, long long* clk_dev) {
   return QMPC_OK;
 }
 
-int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out, void* stream_) {
-  if (!c || !in || !out) return QMPC_ERR_ARG;
+}  // extern "C"
+
+namespace {
+
+bool command_ok(const qmpc_command* cmd) {
+  return cmd->position && cmd->v_world && cmd->omega_world && cmd->orientation && cmd->rpy && cmd->r_body &&
+         cmd->p_foot && cmd->vel_des && cmd->yaw_des_true && cmd->rpy_comp && cmd->gait_offsets &&
+         cmd->gait_durations && cmd->gait_iteration && cmd->world_position_desired && cmd->x_comp_integral &&
+         !(cmd->gait_type && !cmd->stand_traj);  // a standing robot needs its stand_traj row
+}
+
+// one solve: inputs either as the record (`in`) or as the controller command (`cmd`, record built in stage 0)
+int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command* cmd, const qmpc_outputs* out,
+               float* f_ff, void* stream_) {
+  if (!c || (!in && !cmd) || !out) return QMPC_ERR_ARG;
   if (!c->is_setup) return QMPC_ERR_STATE;
   if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
   if (batch == 0) return QMPC_OK;
-  if (!in->p || !in->v || !in->q || !in->w || !in->r || !in->yaw || !in->traj || !in->gait ||
-      !in->weights || !in->alpha || !in->x_drag || !out->grf || !out->status)
+  if (!out->grf || !out->status) return QMPC_ERR_ARG;
+  if (in) {
+    if (!in->p || !in->v || !in->q || !in->w || !in->r || !in->yaw || !in->traj || !in->gait ||
+        !in->weights || !in->alpha || !in->x_drag)
+      return QMPC_ERR_ARG;
+    if ((in->weights_stride != 0 && in->weights_stride != 12) || (in->alpha_stride & ~1) ||
+        (in->x_drag_stride & ~1))
+      return QMPC_ERR_ARG;
+  } else if (!command_ok(cmd)) {
     return QMPC_ERR_ARG;
-  if ((in->weights_stride != 0 && in->weights_stride != 12) || (in->alpha_stride & ~1) ||
-      (in->x_drag_stride & ~1))
-    return QMPC_ERR_ARG;
+  }
   hipStream_t stream = (hipStream_t)stream_;
   DeviceGuard g(c->device);
   const int h = c->horizon;
 
   QmpcParams P;
   std::memset(&P, 0, sizeof(P));
-  P.p = in->p; P.v = in->v; P.q = in->q; P.w = in->w; P.r = in->r; P.yaw = in->yaw;
-  P.traj = in->traj; P.gait = in->gait; P.weights = in->weights; P.alpha = in->alpha;
-  P.x_drag = in->x_drag;
-  P.weights_stride = in->weights_stride;
-  P.alpha_stride = in->alpha_stride;
-  P.x_drag_stride = in->x_drag_stride;
+  if (in) {
+    P.p = in->p; P.v = in->v; P.q = in->q; P.w = in->w; P.r = in->r; P.yaw = in->yaw;
+    P.traj = in->traj; P.gait = in->gait; P.weights = in->weights; P.alpha = in->alpha;
+    P.x_drag = in->x_drag;
+    P.weights_stride = in->weights_stride;
+    P.alpha_stride = in->alpha_stride;
+    P.x_drag_stride = in->x_drag_stride;
+  } else {
+    P.c_position = cmd->position; P.c_v_world = cmd->v_world; P.c_omega_world = cmd->omega_world;
+    P.c_orientation = cmd->orientation; P.c_rpy = cmd->rpy; P.c_r_body = cmd->r_body; P.c_p_foot = cmd->p_foot;
+    P.c_vel_des = cmd->vel_des; P.c_yaw_des_true = cmd->yaw_des_true; P.c_rpy_comp = cmd->rpy_comp;
+    P.c_stand_traj = cmd->stand_traj; P.c_rp_des = cmd->rp_des; P.c_gait_type = cmd->gait_type;
+    P.c_gait_offsets = cmd->gait_offsets; P.c_gait_durations = cmd->gait_durations;
+    P.c_gait_iteration = cmd->gait_iteration; P.c_wpd = cmd->world_position_desired;
+    P.c_xci = cmd->x_comp_integral; P.c_body_height = cmd->body_height; P.c_omni_mode = cmd->omni_mode;
+    P.f_ff = f_ff;
+  }
   P.grf = out->grf; P.soln = out->soln; P.status = out->status; P.iters = out->iters;
   P.batch = batch; P.horizon = h;
   P.dt = c->dt;
@@ -268,16 +297,27 @@ int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outpu
   return QMPC_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int qmpc_solve(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out, void* stream) {
+  if (!in) return QMPC_ERR_ARG;
+  return solve_impl(c, batch, in, nullptr, out, nullptr, stream);
+}
+
+int qmpc_solve_commands(qmpc_handle c, int batch, const qmpc_command* cmd, const qmpc_outputs* out, float* f_ff,
+                        void* stream) {
+  if (!cmd) return QMPC_ERR_ARG;
+  return solve_impl(c, batch, nullptr, cmd, out, f_ff, stream);
+}
+
 int qmpc_pack(qmpc_handle c, int batch, const qmpc_command* cmd, const qmpc_record* rec, void* stream_) {
   if (!c || !cmd || !rec) return QMPC_ERR_ARG;
   if (!c->is_setup) return QMPC_ERR_STATE;
   if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
   if (batch == 0) return QMPC_OK;
-  if (!cmd->position || !cmd->v_world || !cmd->omega_world || !cmd->orientation || !cmd->rpy || !cmd->r_body ||
-      !cmd->p_foot || !cmd->vel_des || !cmd->yaw_des_true || !cmd->rpy_comp || !cmd->gait_offsets ||
-      !cmd->gait_durations || !cmd->gait_iteration || !cmd->world_position_desired || !cmd->x_comp_integral)
-    return QMPC_ERR_ARG;
-  if (cmd->gait_type && !cmd->stand_traj) return QMPC_ERR_ARG;  // a standing robot needs its stand_traj row
+  if (!command_ok(cmd)) return QMPC_ERR_ARG;
   if (!rec->p || !rec->v || !rec->q || !rec->w || !rec->r || !rec->yaw || !rec->traj || !rec->gait || !rec->x_drag)
     return QMPC_ERR_ARG;
   DeviceGuard g(c->device);

@@ -54,6 +54,29 @@ struct QmpcParams {
   int* clear_counts; // class-1 kernel: the two counters of the NEXT call's set, zeroed here
   int* next_list;    // nullptr: no larger class available
   int* next_count;
+  // command mode (qmpc_solve_commands; c_position == nullptr: off): the record is built in
+  // stage 0 from the controller command instead of being loaded (include/qmpc.h qmpc_command)
+  const float* c_position;
+  const float* c_v_world;
+  const float* c_omega_world;
+  const float* c_orientation;
+  const float* c_rpy;
+  const float* c_r_body;
+  const float* c_p_foot;
+  const float* c_vel_des;
+  const float* c_yaw_des_true;
+  const float* c_rpy_comp;
+  const float* c_stand_traj;
+  const float* c_rp_des;
+  const int32_t* c_gait_type;
+  const int32_t* c_gait_offsets;
+  const int32_t* c_gait_durations;
+  const int32_t* c_gait_iteration;
+  float* c_wpd;   // world_position_desired, in/out
+  float* c_xci;   // x_comp_integral, in/out
+  float c_body_height;
+  int c_omni_mode;
+  float* f_ff;    // optional output: -rBody * f per leg
   // debug dump (nullptr = off)
   double* dbg_H;
   double* dbg_g;

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "qmpc_device.h"
+#include "qmpc_cmd.h"
 
 namespace {
 
@@ -268,11 +269,13 @@ struct Smem {
     if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); \
   } while (0)
 
+// CMD selects where the input record comes from: false = loaded (qmpc_solve), true =
+// generated in stage 0 from the controller command (qmpc_solve_commands).
 // V5 selects the active-set engine: true = event form (projected inverse as a
 // sum of rank-1 events; fastest, capacity-limited by the LDS pool), false = the
 // Schur form that never overflows.  Both are run by wave 0 alone.  Returns true
 // when the robot must be re-run with the other engine.
-template <int RB, bool V5>
+template <int RB, bool V5, bool CMD>
 __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW;
@@ -297,24 +300,57 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   const int ek = eidx0 / 12, erow = eidx0 - 12 * ek;
   const int mt = tid % 36, mb = mt / 9, ml = (mt % 9) / 3, max_ = mt % 3;  // (foot, row, axis) of M_b / N_b
   const int hh = h * h;
-  // ---- loads
-  const float g_yaw = PK.yaw[rid];
-  const float g_xdrag = PK.x_drag[(size_t)rid * PK.x_drag_stride];
+  // ---- loads.  Command mode (qmpc_solve_commands): the record is generated here from the
+  // controller command with the arithmetic of qmpc_cmd.h instead of being loaded.
+  constexpr bool cmdm = CMD;  // compile-time: the record path carries no trace of the command mode
+  const float g_yaw = cmdm ? PK.c_rpy[(size_t)rid * 3 + 2] : PK.yaw[rid];
+  const float g_xdrag = cmdm ? PK.c_xci[rid] : PK.x_drag[(size_t)rid * PK.x_drag_stride];
+  float c_p0 = 0.f, c_p1 = 0.f, c_p2 = 0.f;
+  QmpcTrajGen tg;
+  if (cmdm) {
+    const float* pos = PK.c_position + (size_t)rid * 3;
+    c_p0 = pos[0];
+    c_p1 = pos[1];
+    c_p2 = pos[2];
+    const bool stand = PK.c_gait_type && PK.c_gait_type[rid] == 4;
+    float vw0, vw1;
+    qmpc_cmd_vdes_world(PK.c_r_body + (size_t)rid * 9, PK.c_vel_des[(size_t)rid * 3 + 0], PK.c_vel_des[(size_t)rid * 3 + 1],
+                        PK.c_omni_mode, vw0, vw1);
+    qmpc_cmd_traj_gen(tg, stand, stand ? PK.c_stand_traj + (size_t)rid * 6 : nullptr,
+                      PK.c_rp_des ? PK.c_rp_des + (size_t)rid * 2 : nullptr, PK.c_rpy_comp + (size_t)rid * 2,
+                      PK.c_yaw_des_true[rid], PK.c_wpd[(size_t)rid * 2 + 0], PK.c_wpd[(size_t)rid * 2 + 1], c_p0, c_p1,
+                      PK.c_body_height, PK.c_vel_des[(size_t)rid * 3 + 2], vw0, vw1, (float)PK.dt);
+  }
   unsigned char g_gait = 0;
-  if (tid < nfs) g_gait = PK.gait[(size_t)rid * nfs + tid];
+  if (tid < nfs) {
+    if (cmdm) {
+      const int leg = tid & 3;
+      g_gait = (unsigned char)qmpc_cmd_gait_bit(tid >> 2, PK.c_gait_iteration[rid], PK.c_gait_offsets[(size_t)rid * 4 + leg],
+                                                PK.c_gait_durations[(size_t)rid * 4 + leg], h);
+    } else {
+      g_gait = PK.gait[(size_t)rid * nfs + tid];
+    }
+  }
   float g_r0 = 0.f, g_r1 = 0.f, g_r2 = 0.f;
   if (tid < 72) {  // r_feet(axis, foot) = r[axis*4 + foot], RobotState.cpp:25-27
-    const float* r = PK.r + (size_t)rid * 12;
-    g_r0 = r[0 * 4 + mb];
-    g_r1 = r[1 * 4 + mb];
-    g_r2 = r[2 * 4 + mb];
+    if (cmdm) {
+      const float* pf = PK.c_p_foot + (size_t)rid * 12 + 3 * mb;
+      g_r0 = qmpc_cmd_foot_offset(pf[0], c_p0);
+      g_r1 = qmpc_cmd_foot_offset(pf[1], c_p1);
+      g_r2 = qmpc_cmd_foot_offset(pf[2], c_p2);
+    } else {
+      const float* r = PK.r + (size_t)rid * 12;
+      g_r0 = r[0 * 4 + mb];
+      g_r1 = r[1 * 4 + mb];
+      g_r2 = r[2 * 4 + mb];
+    }
   }
   float g_q[4] = {1.f, 0.f, 0.f, 0.f}, g_w[3] = {0.f, 0.f, 0.f}, g_v[3] = {0.f, 0.f, 0.f};
   float g_p = 0.f, g_traj = 0.f, g_wt = 0.f;
   if (e_thr) {
-    const float* q = PK.q + (size_t)rid * 4;
-    const float* om = PK.w + (size_t)rid * 3;
-    const float* v = PK.v + (size_t)rid * 3;
+    const float* q = (cmdm ? PK.c_orientation : PK.q) + (size_t)rid * 4;
+    const float* om = (cmdm ? PK.c_omega_world : PK.w) + (size_t)rid * 3;
+    const float* v = (cmdm ? PK.c_v_world : PK.v) + (size_t)rid * 3;
 #pragma unroll
     for (int k = 0; k < 4; ++k) g_q[k] = q[k];
 #pragma unroll
@@ -322,12 +358,19 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       g_w[k] = om[k];
       g_v[k] = v[k];
     }
-    if (erow >= 3 && erow < 6) g_p = PK.p[(size_t)rid * 3 + (erow - 3)];
-    g_traj = PK.traj[(size_t)rid * 12 * h + eidx0];
-    g_wt = PK.weights[(size_t)rid * PK.weights_stride + erow];
+    if (cmdm) {
+      if (erow >= 3 && erow < 6) g_p = (erow == 3) ? c_p0 : (erow == 4 ? c_p1 : c_p2);
+      g_traj = qmpc_cmd_traj_value(tg, ek, erow);
+      g_wt = qmpc_cmd_weight(erow);
+    } else {
+      if (erow >= 3 && erow < 6) g_p = PK.p[(size_t)rid * 3 + (erow - 3)];
+      g_traj = PK.traj[(size_t)rid * 12 * h + eidx0];
+      g_wt = PK.weights[(size_t)rid * PK.weights_stride + erow];
+    }
   }
   float g_w12 = 0.f;
-  if (tid >= 96 && tid < 96 + 12) g_w12 = PK.weights[(size_t)rid * PK.weights_stride + (tid - 96)];
+  if (tid >= 96 && tid < 96 + 12)
+    g_w12 = cmdm ? qmpc_cmd_weight(tid - 96) : PK.weights[(size_t)rid * PK.weights_stride + (tid - 96)];
   double g_coef = 0.0;
   if (tid >= 112 && tid < 112 + 3 * 16 && ((tid - 112) % 16) < h) g_coef = PK.coef[((tid - 112) / 16) * h + ((tid - 112) % 16)];
   const double x_drag = (double)g_xdrag;
@@ -447,14 +490,35 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   QMPC_TICK(1);
   const int nst = S.nst;
   const int n = 3 * nst;
+  // command mode: what the thread that finalises a robot does besides the outputs --
+  // the controller state owned by the packer (updated once, by the run that produces
+  // the result, so a fallback re-run still reads the old values) ...
+  auto cmd_finish_state = [&]() __attribute__((always_inline)) {
+    // recomputed from memory here rather than carried in registers through the whole solve
+    const float* pos = P.c_position + (size_t)rid * 3;
+    if (!(P.c_gait_type && P.c_gait_type[rid] == 4)) {
+      P.c_wpd[(size_t)rid * 2 + 0] = qmpc_cmd_clamp(P.c_wpd[(size_t)rid * 2 + 0], pos[0]);  // ConvexMPCLocomotion.cpp:534-545
+      P.c_wpd[(size_t)rid * 2 + 1] = qmpc_cmd_clamp(P.c_wpd[(size_t)rid * 2 + 1], pos[1]);
+    }
+    P.c_xci[rid] = qmpc_cmd_xci_next(P.c_xci[rid], pos[2], P.c_body_height, (float)P.dt, P.c_v_world[(size_t)rid * 3 + 0]);
+  };
+  // ... and, optionally, the body-frame forces f_ff[leg] = -rBody * f (:672-680) from the
+  // twelve floats staged in `fb` (lanes 0..11 of one wave)
+  auto cmd_finish_forces = [&](const float* fb, int l12) __attribute__((always_inline)) {
+    const int leg = l12 / 3, ii = l12 - 3 * leg;
+    P.f_ff[(size_t)rid * 12 + l12] =
+        qmpc_cmd_f2b(P.c_r_body + (size_t)rid * 9 + 3 * ii, fb[3 * leg], fb[3 * leg + 1], fb[3 * leg + 2]);
+  };
   if (nst == 0 || n > NP) {
     // all-swing: q_soln is all zeros (SolverMPC.cpp:545-551).  Too large for
     // this instantiation: hand the robot to the next size class.
     if (nst == 0) {
       if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
+      if (cmdm && P.f_ff && tid < 12) P.f_ff[(size_t)rid * 12 + tid] = 0.f;
       if (tid == 0) {
         P.status[rid] = 0;
         if (P.iters) P.iters[rid] = 0;
+        if (cmdm) cmd_finish_state();
       }
     } else if (tid == 0) {
       if (P.next_list) {
@@ -467,8 +531,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     __syncthreads();
     return false;
   }
-  const double alpha = (double)P.alpha[(size_t)rid * P.alpha_stride];
-
+  const double alpha = (double)(cmdm ? 4e-5f : P.alpha[(size_t)rid * P.alpha_stride]);  // ConvexMPCLocomotion.cpp:604
   // ------------------------------------------------------------ stage 1
   // E_00 = B0^T W B0, E_11 = B1^T W B1 in closed form, and the weighted sums
   // s_p[st] = sum_{k>=st} coef_p(k-st) e_k.
@@ -1117,6 +1180,19 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         if (lane == 0) {
           P.status[rid] = S.status | status;
           if (P.iters) P.iters[rid] = iters;
+          if (cmdm) cmd_finish_state();
+        }
+        if (cmdm && P.f_ff) {
+          float* fb = reinterpret_cast<float*>(Sb.D);  // diag(H^-1) is dead now
+          if (lane < 12) fb[lane] = 0.f;
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            const int j = lane + 64 * q;
+            if (j < n && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 12) cmd_finish_forces(fb, lane);
         }
       }
       if (lane == 0) S.mode = retry ? 1 : 0;
@@ -1490,6 +1566,19 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     if (lane == 0) {
       P.status[rid] = S.status | status;
       if (P.iters) P.iters[rid] = iters;
+      if (cmdm) cmd_finish_state();
+    }
+    if (cmdm && P.f_ff) {
+      float* fb = reinterpret_cast<float*>(Sb.D);  // not used by this engine
+      if (lane < 12) fb[lane] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int j = lane + 64 * q;
+        if (j < n && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 12) cmd_finish_forces(fb, lane);
     }
   }
     if (engine && lane == 0) S.mode = 0;
@@ -1507,7 +1596,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 // The list counters are ping-ponged between consecutive solve calls: the
 // class-1 kernel of call N clears the set that call N+1 will use, so no memset
 // and no host round trip is needed.
-template <int RB>
+template <int RB, bool CMD>
 __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void qmpc_solve_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
@@ -1518,22 +1607,26 @@ __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void q
     if ((int)blockIdx.x >= *P.count) return;  // uniform
     rid = P.list[blockIdx.x];
   }
-  if (threadIdx.x == 0) S.par = P;  // visible to all after the first barrier inside solve_one
+  // park the parameter block in LDS, one dword per thread (visible to all after the
+  // first barrier inside solve_one)
+  static_assert(sizeof(QmpcParams) % 4 == 0 && sizeof(QmpcParams) / 4 <= 256, "parameter block copy");
+  if (threadIdx.x < sizeof(QmpcParams) / 4)
+    reinterpret_cast<uint32_t*>(&S.par)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P)[threadIdx.x];
   if constexpr (RB < 3) {
     // projected-inverse engine first; the (rare) robot that runs out of pool is
     // solved again from scratch with the Schur-form engine, which cannot overflow
-    if (solve_one<RB, true>(rid, (int)threadIdx.x, S, P)) {
+    if (solve_one<RB, true, CMD>(rid, (int)threadIdx.x, S, P)) {
       __syncthreads();
       // opaque thread id: without it the compiler keeps per-thread values of the
       // first run alive (spilled to scratch by EVERY workgroup) for this rare second run
       int tid2 = (int)threadIdx.x;
       asm volatile("" : "+v"(tid2));
-      solve_one<RB, false>(rid, tid2, S, P);
+      solve_one<RB, false, CMD>(rid, tid2, S, P);
       __syncthreads();
       if (threadIdx.x == 0) P.status[rid] |= QMPC_DEV_ST_FALLBACK;  // informational
     }
   } else {
-    solve_one<RB, false>(rid, (int)threadIdx.x, S, P);
+    solve_one<RB, false, CMD>(rid, (int)threadIdx.x, S, P);
   }
 }
 
@@ -1546,21 +1639,38 @@ extern "C" size_t qmpc_smem_bytes(int rb) {
   return 0;
 }
 
+namespace {
+template <int RB, bool CMD>
+hipError_t prepare_one() {
+  return hipFuncSetAttribute((const void*)qmpc_solve_kernel<RB, CMD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)sizeof(Smem<RB>));
+}
+template <int RB>
+void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
+  if (cmd)
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true>), dim3(grid), dim3(256 * RB), sizeof(Smem<RB>), stream, *P);
+  else
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false>), dim3(grid), dim3(256 * RB), sizeof(Smem<RB>), stream, *P);
+}
+}  // namespace
+
 extern "C" hipError_t qmpc_prepare(void) {
   hipError_t e;
-  e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<1>));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<2>));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<3>));
-  return e;
+  if ((e = prepare_one<1, false>()) != hipSuccess) return e;
+  if ((e = prepare_one<2, false>()) != hipSuccess) return e;
+  if ((e = prepare_one<3, false>()) != hipSuccess) return e;
+  if ((e = prepare_one<1, true>()) != hipSuccess) return e;
+  if ((e = prepare_one<2, true>()) != hipSuccess) return e;
+  return prepare_one<3, true>();
 }
 
+// the command-mode instantiation is selected by P->c_position != nullptr
 extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
+  const bool cmd = P->c_position != nullptr;
   switch (rb) {
-    case 1: hipLaunchKernelGGL(qmpc_solve_kernel<1>, dim3(grid), dim3(256), sizeof(Smem<1>), stream, *P); break;
-    case 2: hipLaunchKernelGGL(qmpc_solve_kernel<2>, dim3(grid), dim3(512), sizeof(Smem<2>), stream, *P); break;
-    case 3: hipLaunchKernelGGL(qmpc_solve_kernel<3>, dim3(grid), dim3(768), sizeof(Smem<3>), stream, *P); break;
+    case 1: launch_one<1>(cmd, P, grid, stream); break;
+    case 2: launch_one<2>(cmd, P, grid, stream); break;
+    case 3: launch_one<3>(cmd, P, grid, stream); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -418,3 +418,38 @@ def test_class3_working_set_beyond_48_slots(mpc_factory):
         assert rc == 0 and irc == 0
         xs = res["soln"][i][~ve]
         assert np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0) < 1e-8
+
+
+@pytest.mark.parametrize("B,h,omni,stand,calm", [(192, 10, 0, 0.15, False), (70, 16, 1, 0.3, True), (33, 14, 0, 1.0, True)])
+def test_fused_command_solve_is_bit_identical_to_the_three_calls(B, h, omni, stand, calm, mpc_factory):
+    """qmpc_solve_commands (record generated in stage 0, state updated and forces rotated in the
+    same launch) against qmpc_pack -> qmpc_solve -> qmpc_forces_to_body, across all size classes."""
+    import torch
+    cmd = W.make_commands(B, horizon=h, seed=300 + B, omni_mode=omni, stand_fraction=stand, calm=calm)
+    m = mpc_factory(_pack_setup(cmd))
+    # three calls
+    d1 = m.upload_command(cmd)
+    rec = m.alloc_record(B)
+    o1 = m.alloc_outputs(B, full=True)
+    inp, out1 = m.make_args(rec, o1)
+    f1 = torch.empty_like(o1["grf"])
+    m.pack_async(d1, rec)
+    m.solve_async(B, inp, out1)
+    m.forces_to_body_async(B, d1["r_body"], o1["grf"], f1)
+    # one call
+    d2 = m.upload_command(cmd)
+    o2 = m.alloc_outputs(B, full=True)
+    _, out2 = m.make_args(rec, o2)
+    f2 = torch.empty_like(o2["grf"])
+    m.solve_commands_async(B, m.make_command_args(d2), out2, f2)
+    torch.cuda.synchronize()
+    assert ((o2["status"].cpu().numpy() & 15) == 0).all()
+    for k in ("grf", "soln", "status", "iters"):
+        assert torch.equal(o1[k], o2[k]), k
+    assert torch.equal(f1, f2)
+    for k in ("world_position_desired", "x_comp_integral"):
+        assert torch.equal(d1[k], d2[k]), k
+    # and both match the restatement's state update
+    _, wpd, xci = O.pack_commands(cmd, np.float32(0.026))
+    assert np.array_equal(d2["world_position_desired"].cpu().numpy(), wpd)
+    assert np.array_equal(d2["x_comp_integral"].cpu().numpy(), xci)
