@@ -373,6 +373,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     g_w12 = cmdm ? qmpc_cmd_weight(tid - 96) : PK.weights[(size_t)rid * PK.weights_stride + (tid - 96)];
   double g_coef = 0.0;
   if (tid >= 112 && tid < 112 + 3 * 16 && ((tid - 112) % 16) < h) g_coef = PK.coef[((tid - 112) / 16) * h + ((tid - 112) % 16)];
+  // (loaded here with everything else: a global load issued after barrier 1 would be waited
+  //  for by barrier 2)
+  const float g_alpha = cmdm ? 4e-5f : PK.alpha[(size_t)rid * PK.alpha_stride];  // ConvexMPCLocomotion.cpp:604
   const double x_drag = (double)g_xdrag;
   const bool drag = (x_drag != 0.0);
   double g_ct0 = 0.0, g_ct4 = 0.0, g_ct1 = 0.0, g_ct5 = 0.0, g_ct8 = 0.0;
@@ -531,7 +534,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     __syncthreads();
     return false;
   }
-  const double alpha = (double)(cmdm ? 4e-5f : P.alpha[(size_t)rid * P.alpha_stride]);  // ConvexMPCLocomotion.cpp:604
+  const double alpha = (double)g_alpha;
   // ------------------------------------------------------------ stage 1
   // E_00 = B0^T W B0, E_11 = B1^T W B1 in closed form, and the weighted sums
   // s_p[st] = sum_{k>=st} coef_p(k-st) e_k.
