@@ -302,8 +302,13 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   // ---- loads.  Command mode (qmpc_solve_commands): the record is generated here from the
   // controller command with the arithmetic of qmpc_cmd.h instead of being loaded.
   constexpr bool cmdm = CMD;  // compile-time: the record path carries no trace of the command mode
-  const float g_yaw = cmdm ? PK.c_rpy[(size_t)rid * 3 + 2] : PK.yaw[rid];
-  const float g_xdrag = cmdm ? PK.c_xci[rid] : PK.x_drag[(size_t)rid * PK.x_drag_stride];
+  // the parameter block is parked in LDS one dword per thread (read back as `P` after
+  // barrier 1); its load goes out with all the others
+  static_assert(sizeof(QmpcParams) % 4 == 0 && sizeof(QmpcParams) / 4 <= 256, "parameter block copy");
+  uint32_t g_par = 0;
+  if (tid < (int)(sizeof(QmpcParams) / 4)) g_par = reinterpret_cast<const uint32_t*>(&PK)[tid];
+  float g_yaw = cmdm ? PK.c_rpy[(size_t)rid * 3 + 2] : PK.yaw[rid];
+  float g_xdrag = cmdm ? PK.c_xci[rid] : PK.x_drag[(size_t)rid * PK.x_drag_stride];
   float c_p0 = 0.f, c_p1 = 0.f, c_p2 = 0.f;
   QmpcTrajGen tg;
   if (cmdm) {
@@ -372,19 +377,32 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     g_w12 = cmdm ? qmpc_cmd_weight(tid - 96) : PK.weights[(size_t)rid * PK.weights_stride + (tid - 96)];
   // (loaded here with everything else: a global load issued after barrier 1 would be waited
   //  for by barrier 2)
-  const float g_alpha = cmdm ? 4e-5f : PK.alpha[(size_t)rid * PK.alpha_stride];  // ConvexMPCLocomotion.cpp:604
-  const double x_drag = (double)g_xdrag;
-  const bool drag = (x_drag != 0.0);
+  float g_alpha = cmdm ? 4e-5f : PK.alpha[(size_t)rid * PK.alpha_stride];  // ConvexMPCLocomotion.cpp:604
   double g_ct0 = 0.0, g_ct4 = 0.0, g_ct1 = 0.0, g_ct5 = 0.0, g_ct8 = 0.0;
   if (tid < hh) {  // h*h <= 256 == NT for RB = 1; larger classes loop below
+    // the x_drag tables are fetched unconditionally: making them wait for the x_drag
+    // value would put a second memory round trip in front of them
     g_ct0 = PK.ctab[tid];
     g_ct4 = PK.ctab[4 * hh + tid];
-    if (drag) {
-      g_ct1 = PK.ctab[1 * hh + tid];
-      g_ct5 = PK.ctab[5 * hh + tid];
-      g_ct8 = PK.ctab[8 * hh + tid];
-    }
+    g_ct1 = PK.ctab[1 * hh + tid];
+    g_ct5 = PK.ctab[5 * hh + tid];
+    g_ct8 = PK.ctab[8 * hh + tid];
   }
+  // Every load above is in flight now.  The compiler otherwise sinks the first use
+  // of each value (a conversion) into the conditional block of its load and waits for
+  // memory there -- one full round trip per block, eight in a row.  Touching all the
+  // values here, after the last load has been issued, leaves one wait for the lot.
+  {
+    int gg = g_gait;
+    asm volatile("" : "+v"(g_par), "+v"(g_yaw), "+v"(g_xdrag), "+v"(g_alpha), "+v"(gg), "+v"(g_r0), "+v"(g_r1),
+                 "+v"(g_r2), "+v"(g_q[0]), "+v"(g_q[1]), "+v"(g_q[2]), "+v"(g_q[3]), "+v"(g_w[0]), "+v"(g_w[1]),
+                 "+v"(g_w[2]), "+v"(g_v[0]), "+v"(g_v[1]), "+v"(g_v[2]), "+v"(g_p), "+v"(g_traj), "+v"(g_wt),
+                 "+v"(g_w12), "+v"(g_ct0), "+v"(g_ct4), "+v"(g_ct1), "+v"(g_ct5), "+v"(g_ct8));
+    g_gait = (unsigned char)gg;
+  }
+  if (tid < (int)(sizeof(QmpcParams) / 4)) reinterpret_cast<uint32_t*>(&S.par)[tid] = g_par;
+  const double x_drag = (double)g_xdrag;
+  const bool drag = (x_drag != 0.0);
 
   if (dbg_clk && tid == 0) {
     float sink = g_yaw + g_traj + (float)g_gait + (float)g_ct0;
@@ -1624,11 +1642,6 @@ __global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void q
     if ((int)blockIdx.x >= *P.count) return;  // uniform
     rid = P.list[blockIdx.x];
   }
-  // park the parameter block in LDS, one dword per thread (visible to all after the
-  // first barrier inside solve_one)
-  static_assert(sizeof(QmpcParams) % 4 == 0 && sizeof(QmpcParams) / 4 <= 256, "parameter block copy");
-  if (threadIdx.x < sizeof(QmpcParams) / 4)
-    reinterpret_cast<uint32_t*>(&S.par)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P)[threadIdx.x];
   if constexpr (RB < 3) {
     // projected-inverse engine first; the (rare) robot that runs out of pool is
     // solved again from scratch with the Schur-form engine, which cannot overflow
