@@ -294,7 +294,10 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   // everything that needs no LDS input.
   auto& Aa = S.u.aw.a;
   auto& Sw = S.u.aw.w;
-  const int eidx0 = tid;                     // one tracking-error entry per thread (12h <= NT)
+  // one tracking-error entry per thread (12h <= NT), taken by the UPPER half of the block
+  // first: waves 0-1 already carry the stance list, M_b / N_b and the tables, so the
+  // transcendental-heavy error rows run beside them instead of after them
+  const int eidx0 = (tid + NT / 2) % NT;
   const bool e_thr = eidx0 < 12 * h;
   const int ek = eidx0 / 12, erow = eidx0 - 12 * ek;
   const int mt = tid % 36, mb = mt / 9, ml = (mt % 9) / 3, max_ = mt % 3;  // (foot, row, axis) of M_b / N_b
@@ -467,15 +470,15 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       if (row < 3) {
         // x0(0..2) = roll, pitch, yaw from the quaternion (SolverMPC.cpp:257-267, :318)
         const float w = g_q[0], x = g_q[1], y = g_q[2], z = g_q[3];
-        float ang;
-        if (row == 0) {
-          ang = atan2f(2.f * (y * z + w * x), w * w - x * x - y * y + z * z);
-        } else if (row == 1) {
+        // roll and yaw share ONE atan2f evaluation (the rows diverge inside a wave, so two
+        // calls would simply run one after the other); pitch replaces its lane's value
+        const float a_num = (row == 0) ? 2.f * (y * z + w * x) : 2.f * (x * y + w * z);
+        const float a_den = (row == 0) ? (w * w - x * x - y * y + z * z) : (w * w + x * x - y * y - z * z);
+        float ang = atan2f(a_num, a_den);
+        if (row == 1) {
           double asd = -2. * (double)(x * z - w * y);
           if (!(asd < .99999)) asd = .99999;
           ang = asinf((float)asd);
-        } else {
-          ang = atan2f(2.f * (x * y + w * z), w * w + x * x - y * y - z * z);
         }
         const double o0 = g_w[0], o1 = g_w[1], o2 = g_w[2];
         const double rate = (row == 0) ? (cy * o0 + sy * o1) : (row == 1 ? (-sy * o0 + cy * o1) : o2);
