@@ -625,14 +625,11 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   if (dbg_clk && tid == 0) dbg_clk[13] = clock64();
   double a[CW];
   {
-    int si = 0, u = 0, ai = 0;
     const bool rowok = i < n;
-    if (rowok) {
-      const int ki = S.sidx[i / 3];
-      ai = i % 3;
-      si = ki >> 2;
-      u = 3 * (ki & 3) + ai;
-    }
+    const int ki = rowok ? (int)S.sidx[(i / 3) & 63] : 0;  // (i/3 < 64 always; the load is unconditional)
+    const int ai = rowok ? i % 3 : 0;
+    const int si = ki >> 2;
+    const int u = 3 * (ki & 3) + ai;
     const double dm2 = x_drag * inv_m * inv_m;
     // the CW columns of this thread walk at most CW/3 + 2 stance slots: fetch
     // their foot-step ids in one batch, then the table / E loads in groups of 4
@@ -640,7 +637,11 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     const int cslot0 = (c * CW) / 3, cax0 = (c * CW) % 3;
     int kjs[NSL];
 #pragma unroll
-    for (int q = 0; q < NSL; ++q) kjs[q] = (cslot0 + q < nst) ? (int)S.sidx[cslot0 + q] : 0;
+    for (int q = 0; q < NSL; ++q) {  // unconditional (clamped) loads: all in flight together
+      const int sl = cslot0 + q;
+      const int kv = (int)S.sidx[sl < 63 ? sl : 63];
+      kjs[q] = (sl < nst) ? kv : 0;
+    }
     // branch-free element loop (indices are always in range: out-of-range rows /
     // columns read slot 0 and are overwritten by the padding select), so the LDS
     // loads of a group of elements are in flight together.  The (slot, axis) walk
