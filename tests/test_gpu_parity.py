@@ -453,3 +453,22 @@ def test_fused_command_solve_is_bit_identical_to_the_three_calls(B, h, omni, sta
     _, wpd, xci = O.pack_commands(cmd, np.float32(0.026))
     assert np.array_equal(d2["world_position_desired"].cpu().numpy(), wpd)
     assert np.array_equal(d2["x_comp_integral"].cpu().numpy(), xci)
+
+
+@pytest.mark.parametrize("h", [1, 3, 6, 13])
+def test_unusual_horizons(h, mpc_factory):
+    """Horizons other than the reference's 10 / 14 / 16 (mixed gaits, some robots standing)."""
+    cmd = W.make_commands(64, horizon=max(h, 2), seed=40 + h, stand_fraction=0.2, calm=True)
+    if h == 1:                                   # one segment: every foot down
+        cmd["horizon"] = 1
+        cmd["gait_offsets"][:] = 0
+        cmd["gait_durations"][:] = 1
+    b, _, _ = O.pack_commands(cmd, np.float32(0.026))
+    b.update(dt=0.026, mu=0.4, f_max=120.0)
+    m = mpc_factory(b)
+    res = m.solve(b, full=True)
+    assert ((res["status"] & 15) == 0).all()
+    q, nwsr, rc = O.solve_batch(b)
+    assert (rc == 0).all()
+    err = np.abs(res["soln"] - q).max(1) / np.maximum(np.abs(q).max(1), 1.0)
+    assert err.max() < (1e-4 if h <= 10 else 5e-4)
