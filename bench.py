@@ -210,7 +210,7 @@ def main():
     status = o["status"].cpu().numpy()
     iters = o["iters"].cpu().numpy()
     nst = ((rec["gait"].cpu().numpy() if args.caller_side else b["gait"]) != 0).sum(1)
-    n_fail = int(((status & 15) != 0).sum())
+    n_fail = int(((status & 47) != 0).sum())   # QMPC_ST_ERROR_MASK
 
     if rank == 0:
         total_qp = per_gpu * world * args.steps

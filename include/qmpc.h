@@ -54,7 +54,8 @@ extern "C" {
 #define QMPC_ST_FALLBACK 16  /* informational, NOT an error: the robot was solved by the
                                 slower Schur-form engine because the fast engine's
                                 working-set pool was exhausted */
-#define QMPC_ST_ERROR_MASK 15
+#define QMPC_ST_NONFINITE 32 /* the result contains NaN / Inf (non-finite input) */
+#define QMPC_ST_ERROR_MASK (15 | 32)
 
 typedef struct qmpc_ctx* qmpc_handle;
 

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
-ST_ERROR_MASK = 15
+ST_NONFINITE = 32
+ST_ERROR_MASK = 15 | 32
 EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",

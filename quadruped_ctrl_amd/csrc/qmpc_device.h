@@ -11,6 +11,7 @@
 #define QMPC_DEV_ST_INFEASIBLE 4
 #define QMPC_DEV_ST_WS_FULL 8
 #define QMPC_DEV_ST_FALLBACK 16
+#define QMPC_DEV_ST_NONFINITE 32
 
 // leading dimension of the debug dump (largest padded size, 3 * 64)
 #define QMPC_DBG_LD 192

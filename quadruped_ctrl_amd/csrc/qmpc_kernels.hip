@@ -1216,6 +1216,12 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
             if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
           }
         }
+        {
+          bool nf = false;  // NaN / Inf anywhere in the result (non-finite input): report it
+#pragma unroll
+          for (int q = 0; q < RB; ++q) nf |= (lane + 64 * q < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
+          if (__ballot(nf)) status |= QMPC_DEV_ST_NONFINITE;
+        }
         if (lane == 0) {
           P.status[rid] = S.status | status;
           if (P.iters) P.iters[rid] = iters;
@@ -1601,6 +1607,12 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xv[q];
         if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
       }
+    }
+    {
+      bool nf = false;  // NaN / Inf anywhere in the result (non-finite input): report it
+#pragma unroll
+      for (int q = 0; q < RB; ++q) nf |= (lane + 64 * q < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
+      if (__ballot(nf)) status |= QMPC_DEV_ST_NONFINITE;
     }
     if (lane == 0) {
       P.status[rid] = S.status | status;

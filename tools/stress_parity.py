@@ -72,7 +72,7 @@ for name, mk in FAMILIES.items():
         worst = max(worst, np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0))
     st = res["status"]
     print(f"{name:22s} B={B:5d} h={h:2d} worst rel err {worst:.2e} | iters mean {res['iters'].mean():.2f} "
-          f"max {res['iters'].max()} | fallback {int(((st & 16) != 0).sum())} | error status {int(((st & 15) != 0).sum())} "
+          f"max {res['iters'].max()} | fallback {int(((st & 16) != 0).sum())} | error status {int(((st & 47) != 0).sum())} "
           f"| qpOASES failures {nfail}, over its nWSR=100 cap {over}")
     worst_all = max(worst_all, worst)
     m.close()
