@@ -45,6 +45,9 @@ constexpr int WAVE = 64;
 #ifndef QMPC_ENGINE_PRIO
 #define QMPC_ENGINE_PRIO 3
 #endif
+#ifndef QMPC_SWEEP_PRIO
+#define QMPC_SWEEP_PRIO 1
+#endif
 
 // ----------------------------------------------------------------- wave helpers
 // DPP control words (gfx9): row_shr:n = 0x110+n, row_bcast:15 = 0x142,
@@ -766,6 +769,17 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #define QMPC_PIN __builtin_amdgcn_sched_barrier(0)
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
+#if QMPC_SWEEP_PRIO
+      // Issue priority falls as the sweep advances.  Among equal priorities the SIMD
+      // favours its OLDEST wave, so of the four workgroups of a CU the first one
+      // dispatched used to sweep at full speed (24k cycles) and the last one at half
+      // (50k) -- and a launch ends with its slowest workgroup.  A wave that is ahead now
+      // yields to the ones behind it.
+      if (kb == 0) __builtin_amdgcn_s_setprio(3);
+      else if (kb == 1) __builtin_amdgcn_s_setprio(2);
+      else if (kb == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
       StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
         constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
         constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
@@ -830,6 +844,13 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     __syncthreads();
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
+#if QMPC_SWEEP_PRIO
+      // see the class-1 loop: a wave that is ahead yields issue slots to the ones behind it
+      if (kb == 0) __builtin_amdgcn_s_setprio(3);
+      else if (kb == 1) __builtin_amdgcn_s_setprio(2);
+      else if (kb == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
       StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
         constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
         constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;

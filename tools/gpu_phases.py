@@ -42,3 +42,10 @@ print("  iters percentiles", {q: int(np.percentile(it, q)) for q in qs}, " AS cy
 print("  stage 0 detail (tid 0): loads landed %d | compute %d | barrier %d ;  stage 2: g %d | H asm %d" % tuple(
     np.median(x) for x in (c[:,11]-c[:,0], c[:,12]-c[:,11], c[:,1]-c[:,12], c[:,13]-c[:,2], c[:,3]-c[:,13])))
 
+
+fixed = tot - d[:, 5]
+print("  fixed part (total - active set) percentiles", {q: int(np.percentile(fixed, q)) for q in [1, 10, 50, 90, 99, 100]},
+      "| sweep percentiles", {q: int(np.percentile(d[:, 3], q)) for q in [1, 10, 50, 90, 99, 100]})
+slow = np.argsort(tot)[-5:]
+print("  five slowest blocks: total", tot[slow].astype(int).tolist(), "iters", it[slow].tolist(), "sweep", d[slow, 3].astype(int).tolist(),
+      "fixed", fixed[slow].astype(int).tolist())
