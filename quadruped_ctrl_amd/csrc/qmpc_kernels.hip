@@ -48,6 +48,9 @@ constexpr int WAVE = 64;
 #ifndef QMPC_SWEEP_PRIO
 #define QMPC_SWEEP_PRIO 1
 #endif
+#ifndef QMPC_START_PRIO
+#define QMPC_START_PRIO 1
+#endif
 
 // ----------------------------------------------------------------- wave helpers
 // DPP control words (gfx9): row_shr:n = 0x110+n, row_bcast:15 = 0x142,
@@ -289,6 +292,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   const int nfs = 4 * h;   // foot-steps in the horizon (<= 64)
   long long* dbg_clk = PK.dbg_clk ? PK.dbg_clk + (size_t)rid * 16 : nullptr;
   QMPC_TICK(0);
+#if QMPC_SWEEP_PRIO && QMPC_START_PRIO
+  __builtin_amdgcn_s_setprio(3);  // a workgroup that is just starting is behind everybody else on its CU
+#endif
 
   // ------------------------------------------------------------ stage 0
   // Every global load of the robot's record is issued up front (one memory
