@@ -829,7 +829,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
             prod_store(k0 + 2, m + 1);
             QMPC_PIN;
             fmac4_rowbcast<G3>(a, cv1, nu1);
-          } else {
+          } else if (c * CW < n) {
+            // (a column group that lies entirely in the identity padding never changes:
+            //  its pivot-column entries are zero)
             fmac16_rowbcast(a, cv0, nu0);
             fmac16_rowbcast(a, cv1, nu1);
           }
