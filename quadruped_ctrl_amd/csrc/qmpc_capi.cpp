@@ -33,8 +33,8 @@ struct qmpc_ctx {
   int max_iter = 1000;
   double tol = 1e-9;
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
-  int* d_lists = nullptr;      // [2][max_batch] robot ids for classes 2 and 3
-  int* d_counts = nullptr;     // [2 sets][2]: list lengths of classes 2,3, ping-ponged between calls
+  int* d_lists = nullptr;      // [3][max_batch] robot ids handed to classes 4, 2 and 3
+  int* d_counts = nullptr;     // [2 sets][4]: list lengths of classes 4, 2, 3 (+pad), ping-ponged between calls
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   double* dbg_H = nullptr;
@@ -89,9 +89,9 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   DeviceGuard g(device_id);
   const size_t H = (size_t)max_horizon;
   hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
-  if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 2 * (size_t)max_batch);
-  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 4);
-  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 4);
+  if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 3 * (size_t)max_batch);
+  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 8);
+  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 8);
   if (e == hipSuccess) e = qmpc_prepare();
   if (e != hipSuccess) {
     qmpc_destroy(c);
@@ -260,39 +260,37 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_g = c->dbg_g;
   P.dbg_clk = c->dbg_clk;
 
-  // size classes: n_r = 3 * stance foot-steps <= 64 / 128 / 192
+  // size classes by padded rows: 64 (kernel class 1), 96 (class 4), 128 (class 2), 192 (class 3);
+  // n_r = 3 * stance foot-steps.  Every class is launched over the whole batch; a robot that
+  // does not fit appends itself to the list of the next one.
+  static const int chain[4] = {1, 4, 2, 3};
+  static const int rows[4] = {64, 96, 128, 192};
   const int nmax = 12 * h;
-  const int nclass = nmax <= 64 ? 1 : (nmax <= 128 ? 2 : 3);
+  int nclass = 4;
+  for (int k = 0; k < 4; ++k)
+    if (nmax <= rows[k]) { nclass = k + 1; break; }
   // a caller that knows its gaits can bound the reduced size (qmpc_set_max_stance):
   // larger classes are then not even launched; violators are flagged WS_FULL
   int nclass_eff = nclass;
   if (c->max_stance > 0) {
     const int nb = 3 * c->max_stance;
-    const int hc = nb <= 64 ? 1 : (nb <= 128 ? 2 : 3);
+    int hc = 4;
+    for (int k = 0; k < 4; ++k)
+      if (nb <= rows[k]) { hc = k + 1; break; }
     if (hc < nclass_eff) nclass_eff = hc;
   }
-  int* list2 = c->d_lists;
-  int* list3 = c->d_lists + c->max_batch;
   const unsigned set = c->call_no & 1u;
   c->call_no++;
-  int* cnt = c->d_counts + 2 * set;             // this call's counters
-  int* cnt_next = c->d_counts + 2 * (set ^ 1u); // cleared by this call's class-1 kernel
-  // class 1: one workgroup per robot; larger robots are appended to list2
-  P.list = nullptr; P.count = nullptr; P.clear_counts = cnt_next;
-  P.next_list = nclass_eff > 1 ? list2 : nullptr;
-  P.next_count = nclass_eff > 1 ? cnt : nullptr;
-  HIP_TRY(c, qmpc_launch(1, &P, batch, stream));
-  P.clear_counts = nullptr;
-  if (nclass_eff > 1) {
-    P.list = list2; P.count = cnt;
-    P.next_list = nclass_eff > 2 ? list3 : nullptr;
-    P.next_count = nclass_eff > 2 ? cnt + 1 : nullptr;
-    HIP_TRY(c, qmpc_launch(2, &P, batch, stream));
-  }
-  if (nclass_eff > 2) {
-    P.list = list3; P.count = cnt + 1;
-    P.next_list = nullptr; P.next_count = nullptr;
-    HIP_TRY(c, qmpc_launch(3, &P, batch, stream));
+  int* cnt = c->d_counts + 4 * set;             // this call's counters (one per list)
+  int* cnt_next = c->d_counts + 4 * (set ^ 1u); // cleared by this call's first kernel
+  for (int k = 0; k < nclass_eff; ++k) {
+    P.list = k ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
+    P.count = k ? cnt + (k - 1) : nullptr;
+    P.clear_counts = k ? nullptr : cnt_next;
+    const bool more = k + 1 < nclass_eff;
+    P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
+    P.next_count = more ? cnt + k : nullptr;
+    HIP_TRY(c, qmpc_launch(chain[k], &P, batch, stream));
   }
   return QMPC_OK;
 }

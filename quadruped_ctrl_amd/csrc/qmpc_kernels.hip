@@ -158,6 +158,22 @@ __device__ __forceinline__ void fmac4_rowbcast(double (&a)[16], double c, double
       : "v"(c), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3));
 }
 
+// the same for eight accumulators (the 24-column groups of class 4: 16 + 8)
+__device__ __forceinline__ void fmac8_rowbcast(double (&a)[8], double c, double u) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %8, %9 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %8, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %8, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %4, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %5, %8, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %6, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %7, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+      : "v"(c), "v"(u));
+}
+
 // compile-time loop: f(integral_constant<int, R>) for R = 0 .. N-1, so that
 // register-array indices derived from R are constant expressions
 template <int R, int N>
@@ -200,11 +216,17 @@ __device__ __forceinline__ void con_coefs(int e, double mi, int& j1, int& j2, do
   }
 }
 
+// Size classes.  RB names the class: 1, 2, 3 = 64 / 128 / 192 padded rows (four column
+// groups of 16 RB columns, 256 RB threads); 4 = the 96-row class between 1 and 2 (four
+// groups of 24 columns, 384 threads, two workgroups per CU) that catches n_r <= 96 --
+// trot at horizon 16, most random-contact tables -- which class 2 can only run one
+// workgroup per CU.
 template <int RB>
 struct Cfg {
-  static constexpr int NP = 64 * RB;
-  static constexpr int CW = 16 * RB;
-  static constexpr int NT = 256 * RB;
+  static constexpr int NP = (RB == 4) ? 96 : 64 * RB;
+  static constexpr int CW = NP / 4;
+  static constexpr int NT = 4 * NP;
+  static constexpr int RE = (NP + 63) / 64;  // 64-row blocks of an index-major engine vector
   // working-set slots: every n_r <= 64 problem fits 64; in the largest class the
   // 160 KiB of LDS next to the packed inverse set the bound at run time (48 slots at
   // n_r = 192, all 96 at n_r <= 168)
@@ -215,10 +237,12 @@ struct Cfg {
   // doubles of active-set storage behind the packed inverse.  Event-form engine:
   // one (z~, g~) record of NP + KS doubles per working-set change; Schur-form
   // engine: packed S_W^-1 (front) and rows H^-1 c_w (back).  Sized so that
-  // class 1 keeps 4 workgroups per CU
-  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : 1176);
+  // class 1 keeps 4 workgroups per CU and class 4 two
+  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176));
   static constexpr int NPOOL = POOL;
   static constexpr int KS = (RB == 1) ? 32 : 64;  // event-form engine: working-set slot capacity (one per lane)
+  static constexpr bool EVENT_ENGINE = (RB != 3);  // class 3 has no LDS left for events
+  static constexpr int MIN_WAVES = (RB == 1) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
 };
 
 template <int RB>
@@ -283,7 +307,7 @@ struct Smem {
 template <int RB, bool V5, bool CMD>
 __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
-  constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW;
+  constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
   const QmpcParams& P = S.par;  // parked copy: everything after stage 0
   const int lane = tid & (WAVE - 1);
   const int i = tid % NP;  // matrix row owned by this thread
@@ -894,6 +918,14 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
             fmac16_rowbcast(ag, cv0, -u0);
             fmac16_rowbcast(ag, cv1, -u1);
           }
+          if constexpr (CW % 16 == 8) {  // class 4: the last eight columns of the group
+            constexpr int G8 = CW - 8;
+            const double cv0 = cb0[c * CW + G8 + (lane & 7)];
+            const double cv1 = cb1[c * CW + G8 + (lane & 7)];
+            double(&ag)[8] = *reinterpret_cast<double(*)[8]>(&a[G8]);
+            fmac8_rowbcast(ag, cv0, -u0);
+            fmac8_rowbcast(ag, cv1, -u1);
+          }
           if (c == kb) {
             // pivot columns <- F, pivot block <- -P^-1
             a[r0] = p0 ? -i11 : (p1 ? i01 : fg0);
@@ -924,12 +956,12 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   }
   __syncthreads();
   const bool engine = tid < WAVE;
-  double xv[RB];  // engine lane: x[lane + 64 q]
+  double xv[RE];  // engine lane: x[lane + 64 q]
 #pragma unroll
-  for (int q = 0; q < RB; ++q) xv[q] = 0.0;
+  for (int q = 0; q < RE; ++q) xv[q] = 0.0;
   if (engine) {
 #pragma unroll
-    for (int q = 0; q < RB; ++q) {
+    for (int q = 0; q < RE; ++q) {
       const int j = lane + 64 * q;
       if (j < n) xv[q] = Sw.part[0][j] + Sw.part[1][j] + Sw.part[2][j] + Sw.part[3][j];
     }
@@ -992,7 +1024,17 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
   bool retry = false;
   if constexpr (V5) {
     if (engine) {
-      constexpr int KS = C::KS, EV = NP + KS, KEV = (C::NPOOL / EV) & ~3;
+      constexpr int NPE = NP, KS = C::KS, EV = NPE + KS, KEV = (C::NPOOL / EV) & ~3;
+      // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
+      // 96 rows in two 64-lane blocks) read entry 0 -- harmless, those rows are never used -- and
+      // do not write
+      int zo[RE];
+      bool zw[RE];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) {
+        zw[q] = lane + 64 * q < NP;
+        zo[q] = zw[q] ? lane + 64 * q : 0;
+      }
       double* const pool = Sb.Sinv;
       const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
       const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
@@ -1007,21 +1049,21 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       bool need_p = true;
       int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
       double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
-      int rbl[RB];
+      int rbl[RE];
 #pragma unroll
-      for (int q = 0; q < RB; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
-      const int gl_off = NP + (lane & (KS - 1));  // this lane's entry of an event's g~
-      auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+      for (int q = 0; q < RE; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
+      const int gl_off = NPE + (lane & (KS - 1));  // this lane's entry of an event's g~
+      auto gather = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
         double out = 0.0;
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
+        for (int q = 0; q < RE; ++q) {
           const double cand = __shfl(v[q], j & 63);
           if ((j >> 6) == q) out = cand;
         }
         return out;
       };
-      auto bcast = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
-        return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
+      auto bcast = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
+        return readlane_f64(pick<RE>(v, (j >> 6) < RE ? (j >> 6) : 0), j & 63);
       };
       // element (row = lane + 64 q, column j) of H^-1 for a wave-uniform j
       auto Hcol = [&](int q, int j) __attribute__((always_inline)) {
@@ -1086,9 +1128,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         }
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
         // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
-        double z[RB];
+        double z[RE];
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
+        for (int q = 0; q < RE; ++q) {
           const int row = lane + 64 * q;
           z[q] = (row < n) ? __builtin_fma(pa2, Hcol(q, pj2), pa1 * Hcol(q, pj1)) : 0.0;
         }
@@ -1100,21 +1142,21 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll 1
           for (int t0 = 0; t0 < cnt; t0 += 4) {
             const double* ev = pool + (base + DIR * t0) * EV;
-            double ya[4], yb[4], zl[4][RB], gl[4];
+            double ya[4], yb[4], zl[4][RE], gl[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const double* eu = ev + DIR * u * EV;
               ya[u] = eu[pj1];
               yb[u] = eu[pj2];
 #pragma unroll
-              for (int q = 0; q < RB; ++q) zl[u][q] = eu[lane + 64 * q];
+              for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
               gl[u] = eu[gl_off];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
 #pragma unroll
-              for (int q = 0; q < RB; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
+              for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
               rw = __builtin_fma(y, gl[u], rw);
             }
           }
@@ -1145,7 +1187,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         }
         if (!dep) {
 #pragma unroll
-          for (int q = 0; q < RB; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
+          for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
         }
         lam -= t * rw;
         lp += t;
@@ -1161,8 +1203,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           const double s = rsqrt_full(delta);
           double* en = pool + neva * EV;
 #pragma unroll
-          for (int q = 0; q < RB; ++q) en[lane + 64 * q] = z[q] * s;
-          if (lane < KS) en[NP + lane] = (lane == qslot) ? s : ((wcid >= 0) ? -rw * s : 0.0);
+          for (int q = 0; q < RE; ++q)
+            if (zw[q]) en[zo[q]] = z[q] * s;
+          if (lane < KS) en[NPE + lane] = (lane == qslot) ? s : ((wcid >= 0) ? -rw * s : 0.0);
           if (lane == qslot) {
             wcid = p_e;
             lam = lp;
@@ -1178,27 +1221,27 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
             break;
           }
           // u = N*_l (index-major lanes), sc = S^-1[:, l] (slot lanes)
-          double u[RB], sc = 0.0;
+          double u[RE], sc = 0.0;
 #pragma unroll
-          for (int q = 0; q < RB; ++q) u[q] = 0.0;
+          for (int q = 0; q < RE; ++q) u[q] = 0.0;
           auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;
 #pragma unroll 1
             for (int t0 = 0; t0 < cnt; t0 += 4) {
               const double* ev = pool + (base + DIR * t0) * EV;
-              double gll[4], zl[4][RB], gw[4];
+              double gll[4], zl[4][RE], gw[4];
 #pragma unroll
               for (int u4 = 0; u4 < 4; ++u4) {
                 const double* eu = ev + DIR * u4 * EV;
-                gll[u4] = eu[NP + l];
+                gll[u4] = eu[NPE + l];
 #pragma unroll
-                for (int q = 0; q < RB; ++q) zl[u4][q] = eu[lane + 64 * q];
+                for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
                 gw[u4] = eu[gl_off];
               }
 #pragma unroll
               for (int u4 = 0; u4 < 4; ++u4) {
 #pragma unroll
-                for (int q = 0; q < RB; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
+                for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
                 sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
               }
             }
@@ -1214,11 +1257,12 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           const int de = __builtin_amdgcn_readlane(wcid, l);
           double* en = pool + (KEV - 1 - nevd) * EV;
 #pragma unroll
-          for (int q = 0; q < RB; ++q) en[lane + 64 * q] = u[q] * sg;
-          if (lane < KS) en[NP + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
+          for (int q = 0; q < RE; ++q)
+            if (zw[q]) en[zo[q]] = u[q] * sg;
+          if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
           // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
-          if (lane < neva) pool[lane * EV + NP + l] = 0.0;
-          if (lane < nevd) pool[(KEV - 1 - lane) * EV + NP + l] = 0.0;
+          if (lane < neva) pool[lane * EV + NPE + l] = 0.0;
+          if (lane < nevd) pool[(KEV - 1 - lane) * EV + NPE + l] = 0.0;
           if (lane == l) {
             wcid = -1;
             lam = 0.0;
@@ -1237,7 +1281,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
+        for (int q = 0; q < RE; ++q) {
           const int j = lane + 64 * q;
           if (j < n) {
             const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
@@ -1248,7 +1292,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         {
           bool nf = false;  // NaN / Inf anywhere in the result (non-finite input): report it
 #pragma unroll
-          for (int q = 0; q < RB; ++q) nf |= (lane + 64 * q < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
+          for (int q = 0; q < RE; ++q) nf |= (lane + 64 * q < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
           if (__ballot(nf)) status |= QMPC_DEV_ST_NONFINITE;
         }
         if (lane == 0) {
@@ -1261,7 +1305,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           if (lane < 12) fb[lane] = 0.f;
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int q = 0; q < RB; ++q) {
+          for (int q = 0; q < RE; ++q) {
             const int j = lane + 64 * q;
             if (j < n && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
           }
@@ -1290,9 +1334,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       const int hi = r > cidx ? r : cidx, lo = r > cidx ? cidx : r;
       return Sb.Hp[hi * (hi + 1) / 2 + lo];
     };
-    int rbl[RB];  // packed-row base of this lane's variables
+    int rbl[RE];  // packed-row base of this lane's variables
 #pragma unroll
-    for (int q = 0; q < RB; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
+    for (int q = 0; q < RE; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
     // element (row = lane + 64 q, column j) of H^-1 for a wave-uniform j
     auto Hcol = [&](int q, int j) __attribute__((always_inline)) {
       const int row = lane + 64 * q;
@@ -1300,18 +1344,18 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       return Sb.Hp[(j <= row) ? rbl[q] + j : tj + row];
     };
     // value of the index-major vector v at variable j (per-lane j): a bpermute per 64-block
-    auto gather = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
+    auto gather = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
       double out = 0.0;
 #pragma unroll
-      for (int q = 0; q < RB; ++q) {
+      for (int q = 0; q < RE; ++q) {
         const double cand = __shfl(v[q], j & 63);
         if ((j >> 6) == q) out = cand;
       }
       return out;
     };
     // the same for a wave-uniform j
-    auto bcast = [&](const double (&v)[RB], int j) __attribute__((always_inline)) {
-      return readlane_f64(pick<RB>(v, (j >> 6) < RB ? (j >> 6) : 0), j & 63);
+    auto bcast = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
+      return readlane_f64(pick<RE>(v, (j >> 6) < RE ? (j >> 6) : 0), j & 63);
     };
     // row w of M = H^-1 C_W lives at the back of the pool while it does not collide with S_W^-1
     // The packed inverse only occupies n(n+1)/2 doubles of Hp: the working-set storage
@@ -1320,7 +1364,8 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     const int nh = n * (n + 1) / 2;
     double* const swp = Sb.Hp + nh;                      // packed S_W^-1, growing from the front
     const int cap = C::NH + C::NPOOL - nh;              // doubles available
-    auto m_row = [&](int w) __attribute__((always_inline)) { return swp + cap - NP * (w + 1); };
+    constexpr int NPE = 64 * RE;  // row stride of M: a lane never indexes past its row
+    auto m_row = [&](int w) __attribute__((always_inline)) { return swp + cap - NPE * (w + 1); };
 
     unsigned amask = 0;  // stance-slot lane: bit ty = constraint (sl, ty) is in the working set
     int wcid[KW];        // working-slot lane: constraint id in slot w + 64 q, -1 = free
@@ -1380,9 +1425,9 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
 
       // hc = H^-1 c_p, index-major
-      double hc[RB];
+      double hc[RE];
 #pragma unroll
-      for (int q = 0; q < RB; ++q) {
+      for (int q = 0; q < RE; ++q) {
         const int row = lane + 64 * q;
         hc[q] = (row < n) ? pa1 * Hcol(q, pj1) + (two ? pa2 * Hcol(q, pj2) : 0.0) : 0.0;
       }
@@ -1427,23 +1472,23 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         for (int q = 0; q < KW; ++q)
           if (wcid[q] < 0) rw[q] = 0.0;
         // z = H^-1 (c_p - C_W r) = hc - sum_w r_w (H^-1 c_w), index-major
-        double z[RB];
+        double z[RE];
 #pragma unroll
-        for (int q = 0; q < RB; ++q) z[q] = hc[q];
+        for (int q = 0; q < RE; ++q) z[q] = hc[q];
         {
           const int wfast = khw < mvalid ? khw : mvalid;
           for (int w0 = 0; w0 < wfast; w0 += 4) {  // stored rows: one load per lane and slot
-            double mv[4][RB];
+            double mv[4][RE];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-              for (int q = 0; q < RB; ++q) mv[u][q] = (w0 + u < wfast) ? m_row(w0 + u)[lane + 64 * q] : 0.0;
+              for (int q = 0; q < RE; ++q) mv[u][q] = (w0 + u < wfast) ? m_row(w0 + u)[lane + 64 * q] : 0.0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int w = w0 + u;
               const double rv = (w < wfast) ? readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63) : 0.0;
 #pragma unroll
-              for (int q = 0; q < RB; ++q) z[q] = __builtin_fma(-rv, mv[u][q], z[q]);
+              for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(-rv, mv[u][q], z[q]);
             }
           }
           for (int w = wfast; w < khw; ++w) {  // rows that did not fit the pool: recompute from Hp
@@ -1454,7 +1499,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
             double a1, a2;
             con_coefs(e, mi, j1, j2, a1, a2);
 #pragma unroll
-            for (int q = 0; q < RB; ++q) {
+            for (int q = 0; q < RE; ++q) {
               const int row = lane + 64 * q;
               if (row < n) {
                 const double hw = a1 * Hcol(q, j1) + (a2 != 0.0 ? a2 * Hcol(q, j2) : 0.0);
@@ -1502,7 +1547,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         }
         if (!dep) {
 #pragma unroll
-          for (int q = 0; q < RB; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
+          for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
         }
 #pragma unroll
         for (int q = 0; q < KW; ++q) lam[q] -= t * rw[q];
@@ -1526,7 +1571,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           // the packed S_W^-1 grows with the high-water mark: rows of M it would
           // overwrite are given up first
           {
-            const int room = (cap - kn * (kn + 1) / 2) / NP;  // rows of M that still fit behind it
+            const int room = (cap - kn * (kn + 1) / 2) / NPE;  // rows of M that still fit behind it
             const int want = (qslot == mvalid) ? mvalid + 1 : mvalid;
             mvalid = want < room ? want : (mvalid < room ? mvalid : room);
             if (mvalid < 0) mvalid = 0;
@@ -1563,7 +1608,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           }
           if (qslot < mvalid) {
 #pragma unroll
-            for (int q = 0; q < RB; ++q) m_row(qslot)[lane + 64 * q] = hc[q];
+            for (int q = 0; q < RE; ++q) m_row(qslot)[lane + 64 * q] = hc[q];
           }
 #pragma unroll
           for (int q = 0; q < KW; ++q)
@@ -1629,7 +1674,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < RB; ++q) {
+    for (int q = 0; q < RE; ++q) {
       const int j = lane + 64 * q;
       if (j < n) {
         const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
@@ -1640,7 +1685,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     {
       bool nf = false;  // NaN / Inf anywhere in the result (non-finite input): report it
 #pragma unroll
-      for (int q = 0; q < RB; ++q) nf |= (lane + 64 * q < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
+      for (int q = 0; q < RE; ++q) nf |= (lane + 64 * q < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
       if (__ballot(nf)) status |= QMPC_DEV_ST_NONFINITE;
     }
     if (lane == 0) {
@@ -1653,7 +1698,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       if (lane < 12) fb[lane] = 0.f;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int q = 0; q < RB; ++q) {
+      for (int q = 0; q < RE; ++q) {
         const int j = lane + 64 * q;
         if (j < n && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
       }
@@ -1677,17 +1722,17 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 // class-1 kernel of call N clears the set that call N+1 will use, so no memset
 // and no host round trip is needed.
 template <int RB, bool CMD>
-__global__ __launch_bounds__(256 * RB, (RB == 1) ? 4 : (RB == 2 ? 2 : 3)) void qmpc_solve_kernel(const QmpcParams P) {
+__global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   int rid = (int)blockIdx.x;
   if constexpr (RB == 1) {
-    if (blockIdx.x == 0 && threadIdx.x < 2 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 3 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // one counter per deferred-class list
   } else {
     if ((int)blockIdx.x >= *P.count) return;  // uniform
     rid = P.list[blockIdx.x];
   }
-  if constexpr (RB < 3) {
+  if constexpr (Cfg<RB>::EVENT_ENGINE) {
     // projected-inverse engine first; the (rare) robot that runs out of pool is
     // solved again from scratch with the Schur-form engine, which cannot overflow
     if (solve_one<RB, true, CMD>(rid, (int)threadIdx.x, S, P)) {
@@ -1710,6 +1755,7 @@ extern "C" size_t qmpc_smem_bytes(int rb) {
     case 1: return sizeof(Smem<1>);
     case 2: return sizeof(Smem<2>);
     case 3: return sizeof(Smem<3>);
+    case 4: return sizeof(Smem<4>);
   }
   return 0;
 }
@@ -1723,9 +1769,9 @@ hipError_t prepare_one() {
 template <int RB>
 void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
   if (cmd)
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true>), dim3(grid), dim3(256 * RB), sizeof(Smem<RB>), stream, *P);
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
   else
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false>), dim3(grid), dim3(256 * RB), sizeof(Smem<RB>), stream, *P);
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
 }
 }  // namespace
 
@@ -1734,6 +1780,8 @@ extern "C" hipError_t qmpc_prepare(void) {
   if ((e = prepare_one<1, false>()) != hipSuccess) return e;
   if ((e = prepare_one<2, false>()) != hipSuccess) return e;
   if ((e = prepare_one<3, false>()) != hipSuccess) return e;
+  if ((e = prepare_one<4, false>()) != hipSuccess) return e;
+  if ((e = prepare_one<4, true>()) != hipSuccess) return e;
   if ((e = prepare_one<1, true>()) != hipSuccess) return e;
   if ((e = prepare_one<2, true>()) != hipSuccess) return e;
   return prepare_one<3, true>();
@@ -1746,6 +1794,7 @@ extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStre
     case 1: launch_one<1>(cmd, P, grid, stream); break;
     case 2: launch_one<2>(cmd, P, grid, stream); break;
     case 3: launch_one<3>(cmd, P, grid, stream); break;
+    case 4: launch_one<4>(cmd, P, grid, stream); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -262,12 +262,12 @@ def test_size_hint(mpc_factory):
     nst = (b["gait"] != 0).sum(1)
     m.set_max_stance(int(nst.max()))
     ok = m.solve(b, full=True)
-    assert np.array_equal(ok["grf"], base["grf"]) and (ok["status"] == 0).all()
+    assert np.array_equal(ok["grf"], base["grf"]) and ((ok["status"] & 47) == 0).all()
     m.set_max_stance(21)                             # only class 1 (n_r <= 63) is launched
     cut = m.solve(b, full=True)
     big = nst > 21
     assert big.any() and (~big).any()
-    assert np.all(cut["status"][big] == 8) and np.all(cut["status"][~big] == 0)
+    assert np.all(cut["status"][big] == 8) and np.all((cut["status"][~big] & 47) == 0)
     assert np.array_equal(cut["grf"][~big], base["grf"][~big])
     m.set_max_stance(0)
     again = m.solve(b, full=True)                    # back to all classes; lists re-arm themselves
