@@ -112,7 +112,7 @@ int qmpc_set_robot(qmpc_handle h, double mass, const double ibody_diag[3],
 int qmpc_settings(qmpc_handle h, int max_iter, double tol);
 
 /* Optional size hint.  The kernels are specialised by reduced problem size
- * n_r = 3 * (stance foot-steps in the horizon) <= 64 / 128 / 192; without a
+ * n_r = 3 * (stance foot-steps in the horizon) <= 64 / 96 / 128 / 192; without a
  * hint every class that the horizon allows is launched (the unused ones exit
  * at once).  A caller that knows its contact tables (e.g. trot: 2 feet x h)
  * states the bound and the larger classes are skipped; a robot that exceeds

@@ -6,8 +6,8 @@
 // which runs it for ONE robot on one CPU core through Eigen + qpOASES.
 //
 // Design (DESIGN.md has the derivations and measurements):
-//   * one workgroup per robot, NT = 256*RB threads, RB in {1,2,3} selected by
-//     the reduced problem size n_r = 3 * (#stance foot-steps) <= 64*RB.
+//   * one workgroup per robot, matrix padded to NP = 64 / 96 / 128 / 192 rows (size classes
+//     1 / 4 / 2 / 3, NT = 4 NP threads) by the reduced problem size n_r = 3 * (#stance foot-steps).
 //   * the n_r x n_r Hessian lives in REGISTERS for the whole solve: thread
 //     (row i, column group c) owns H[i][c*CW .. c*CW+CW-1].  LDS only carries
 //     vectors (pivot columns, mat-vec operands) and the small working-set
@@ -1716,7 +1716,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 }  // namespace
 
 // Class 1 (RB == 1): one workgroup per robot, robot = blockIdx.x.
-// Classes 2, 3: workgroup b takes entry b of the list of robots the previous
+// Classes 4, 2, 3: workgroup b takes entry b of the list of robots the previous
 // class deferred (grid = batch; workgroups past the list length exit at once).
 // The list counters are ping-ponged between consecutive solve calls: the
 // class-1 kernel of call N clears the set that call N+1 will use, so no memset

@@ -490,3 +490,31 @@ def test_non_finite_input_is_contained(mpc_factory):
     assert ((res["status"][bad] & 47) != 0).all()               # reported: NOT_PD (2) and / or NONFINITE (32)
     assert np.array_equal(res["soln"][~bad], ref["soln"][~bad])  # everybody else bit-identical
     assert (res["iters"][bad] <= 1000).all()
+
+
+def test_size_class_chain(mpc_factory):
+    """One batch whose robots land in every size class and on every class boundary
+    (n_r = 3 * stance foot-steps: 60, 63 | 66, 96 | 99, 126 | 129, 168 at horizon 14)."""
+    h, counts = 14, [20, 21, 22, 32, 33, 42, 43, 56]
+    B = 8 * len(counts)
+    rng = np.random.default_rng(123)
+    b = W.make_config(1, batch=B)                 # states only; horizon / tables replaced below
+    d = W._states(rng, B, h)
+    g = np.zeros((B, 4 * h), np.uint8)
+    for i in range(B):
+        k = counts[i % len(counts)]
+        idx = rng.permutation(4 * h)[:k]
+        g[i, idx] = 1
+        if g[i, :4].sum() == 0:                   # at least one foot down at step 0
+            g[i, idx[0]] = 0
+            g[i, rng.integers(0, 4)] = 1
+    b = W._finish(d, B, h, g)
+    m = mpc_factory(b)
+    res = m.solve(b, full=True)
+    assert ((res["status"] & 47) == 0).all()
+    q, nwsr, rc = O.solve_batch(b)
+    assert (rc == 0).all()
+    err = np.abs(res["soln"] - q).max(1) / np.maximum(np.abs(q).max(1), 1.0)
+    assert err.max() < 5e-4
+    nst = (b["gait"] != 0).sum(1)
+    assert set(nst.tolist()) == set(counts)
