@@ -122,8 +122,10 @@ def main():
     mpc = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=16)
     mpc.setup(b["dt"], h, b["mu"], b["f_max"])
     max_stance = int((b["gait"] != 0).sum(1).max())
+    min_stance = int((b["gait"] != 0).sum(1).min())
     if not args.no_hint:
-        mpc.set_max_stance(max_stance)     # the caller built the contact tables, it knows their bound
+        mpc.set_max_stance(max_stance)     # the caller built the contact tables, it knows their bounds
+        mpc.set_min_stance(min_stance)
     d = mpc.upload(b)
     o = mpc.alloc_outputs(per_gpu, full=False, iters=True)
     inp, out = mpc.make_args(d, o)
@@ -138,6 +140,7 @@ def main():
         max_stance = int(max(np.minimum(cmd["gait_durations"], h).sum(1).max(), 1))
         if not args.no_hint:
             mpc.set_max_stance(max_stance)
+        mpc.set_min_stance(0)
         solve_only = mpc.solve_async
 
         cs = mpc.make_command_args(dcmd)
@@ -195,6 +198,7 @@ def main():
         mpc2.setup(b["dt"], h, b["mu"], b["f_max"])
         if not args.no_hint:
             mpc2.set_max_stance(max_stance)
+            mpc2.set_min_stance(min_stance)
         o2 = mpc2.alloc_outputs(per_gpu, full=False, iters=True)
         inp2, out2 = mpc2.make_args(d, o2)            # same resident inputs, its own outputs
         ctx.append((mpc2, inp2, out2))

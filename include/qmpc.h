@@ -118,6 +118,11 @@ int qmpc_settings(qmpc_handle h, int max_iter, double tol);
  * states the bound and the larger classes are skipped; a robot that exceeds
  * it is reported with QMPC_ST_WS_FULL instead of being solved.  0 = no hint. */
 int qmpc_set_max_stance(qmpc_handle h, int max_stance_footsteps);
+/* Companion lower bound: when every robot has at least this many stance foot-steps, the
+ * classes that are too small for all of them are not launched either (e.g. trot at
+ * horizon 16: 32 foot-steps, n_r = 96 -> the 64-row class would only hand every robot on).
+ * A robot below the bound is still solved correctly.  0 = no hint. */
+int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 
 /* Solve `batch` independent MPC problems.  All pointers are DEVICE pointers
  * valid on the handle's device; the call only enqueues work on `stream`

@@ -20,7 +20,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
-           "qmpc_forces_to_body", "qmpc_solve_commands"]
+           "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance"]
 
 # qmpc_command fields (include/qmpc.h), in declaration order
 CMD_F32 = ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot",
@@ -80,6 +80,7 @@ def load_library():
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_min_stance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_pack.argtypes = [C.c_void_p, C.c_int, C.POINTER(Command), C.POINTER(Record), C.c_void_p]
         lib.qmpc_solve_commands.argtypes = [C.c_void_p, C.c_int, C.POINTER(Command), C.POINTER(Outputs), C.c_void_p,
                                             C.c_void_p]
@@ -142,6 +143,10 @@ class BatchedConvexMPC:
     def set_max_stance(self, max_stance_footsteps):
         """Caller's bound on stance foot-steps per robot (0 = unknown)."""
         self._check(self.lib.qmpc_set_max_stance(self.h, int(max_stance_footsteps)), "qmpc_set_max_stance")
+
+    def set_min_stance(self, min_stance_footsteps):
+        """Caller's lower bound on stance foot-steps per robot (0 = unknown)."""
+        self._check(self.lib.qmpc_set_min_stance(self.h, int(min_stance_footsteps)), "qmpc_set_min_stance")
 
     def settings(self, max_iter=1000, tol=1e-9):
         self._check(self.lib.qmpc_settings(self.h, max_iter, tol), "qmpc_settings")

@@ -37,6 +37,7 @@ struct qmpc_ctx {
   int* d_counts = nullptr;     // [2 sets][4]: list lengths of classes 4, 2, 3 (+pad), ping-ponged between calls
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
+  int min_stance = 0;          // ... and lower bound (0 = unknown)
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
   long long* dbg_clk = nullptr;
@@ -72,7 +73,7 @@ int fail(qmpc_ctx* c, hipError_t e, const char* what) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 3; }
+int qmpc_abi_version(void) { return 4; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -169,6 +170,12 @@ int qmpc_settings(qmpc_handle c, int max_iter, double tol) {
 int qmpc_set_max_stance(qmpc_handle c, int max_stance_footsteps) {
   if (!c || max_stance_footsteps < 0) return QMPC_ERR_ARG;
   c->max_stance = max_stance_footsteps;
+  return QMPC_OK;
+}
+
+int qmpc_set_min_stance(qmpc_handle c, int min_stance_footsteps) {
+  if (!c || min_stance_footsteps < 0) return QMPC_ERR_ARG;
+  c->min_stance = min_stance_footsteps;
   return QMPC_OK;
 }
 
@@ -283,10 +290,13 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   c->call_no++;
   int* cnt = c->d_counts + 4 * set;             // this call's counters (one per list)
   int* cnt_next = c->d_counts + 4 * (set ^ 1u); // cleared by this call's first kernel
-  for (int k = 0; k < nclass_eff; ++k) {
-    P.list = k ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
-    P.count = k ? cnt + (k - 1) : nullptr;
-    P.clear_counts = k ? nullptr : cnt_next;
+  // ... and with a lower bound the classes that are too small for every robot are skipped
+  int k0 = 0;
+  while (k0 + 1 < nclass_eff && 3 * c->min_stance > rows[k0]) ++k0;
+  for (int k = k0; k < nclass_eff; ++k) {
+    P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
+    P.count = k > k0 ? cnt + (k - 1) : nullptr;
+    P.clear_counts = k > k0 ? nullptr : cnt_next;
     const bool more = k + 1 < nclass_eff;
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;

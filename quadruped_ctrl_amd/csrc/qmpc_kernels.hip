@@ -1725,12 +1725,16 @@ template <int RB, bool CMD>
 __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  // the first class launched takes robot = blockIdx.x and clears the NEXT call's list counters;
+  // every later class takes entry blockIdx.x of the list the previous classes filled
   int rid = (int)blockIdx.x;
-  if constexpr (RB == 1) {
-    if (blockIdx.x == 0 && threadIdx.x < 3 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // one counter per deferred-class list
-  } else {
-    if ((int)blockIdx.x >= *P.count) return;  // uniform
-    rid = P.list[blockIdx.x];
+  // (block index first: only block 0 waits for the kernel argument)
+  if (blockIdx.x == 0 && threadIdx.x < 3 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // one counter per list
+  if constexpr (RB != 1) {  // (class 1 is only ever launched first)
+    if (P.list) {
+      if ((int)blockIdx.x >= *P.count) return;  // uniform
+      rid = P.list[blockIdx.x];
+    }
   }
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
     // projected-inverse engine first; the (rare) robot that runs out of pool is

@@ -270,6 +270,14 @@ def test_size_hint(mpc_factory):
     assert np.all(cut["status"][big] == 8) and np.all((cut["status"][~big] & 47) == 0)
     assert np.array_equal(cut["grf"][~big], base["grf"][~big])
     m.set_max_stance(0)
+    m.set_min_stance(int(nst.min()))                 # a correct lower bound changes nothing
+    lo = m.solve(b, full=True)
+    assert np.array_equal(lo["grf"], base["grf"])
+    m.set_min_stance(25)                             # too high for some robots: the 64-row class is skipped,
+    hi = m.solve(b, full=True)                       # ... they are solved by a larger class all the same
+    assert (nst < 22).any() and ((hi["status"] & 47) == 0).all()
+    assert np.abs(hi["grf"] - base["grf"]).max() <= 1e-9 * np.abs(base["grf"]).max()
+    m.set_min_stance(0)
     again = m.solve(b, full=True)                    # back to all classes; lists re-arm themselves
     assert np.array_equal(again["grf"], base["grf"])
     for _ in range(3):                               # repeated calls reuse the ping-ponged counters
