@@ -103,8 +103,14 @@ def main():
                              "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # QMPC_BENCH_BACKEND=gloo + fewer GPUs than ranks: dry run of the N>1 path on a smaller box
+        backend = os.environ.get("QMPC_BENCH_BACKEND", "nccl")
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = local if args.gpus > 1 else 0
     torch.cuda.set_device(dev)
 

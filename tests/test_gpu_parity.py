@@ -526,3 +526,22 @@ def test_size_class_chain(mpc_factory):
     assert err.max() < 5e-4
     nst = (b["gait"] != 0).sum(1)
     assert set(nst.tolist()) == set(counts)
+
+
+def test_bench_two_ranks_dry_run():
+    """The N>1 path of bench.py end to end (rendezvous, per-rank shard, barrier + MAX timing,
+    rank-0 JSON) with two ranks sharing this box's GPU over gloo; on an 8-GPU node the same
+    code runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, QMPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "50", "--warmup", "5", "--settle", "0"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["failed"] == 0
+    assert d["value"] > 1e6 and "cpu_baseline" not in d
