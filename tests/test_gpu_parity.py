@@ -545,3 +545,33 @@ def test_bench_two_ranks_dry_run():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["failed"] == 0
     assert d["value"] > 1e6 and "cpu_baseline" not in d
+
+
+def test_empty_batch_and_argument_errors(mpc_factory):
+    """batch = 0 is a no-op; bad arguments are refused with QMPC_ERR_ARG, nothing is launched."""
+    import torch
+    b = W.make_config(1, batch=8)
+    m = mpc_factory(b)
+    d = m.upload(b)
+    o = m.alloc_outputs(8, full=False)
+    o["grf"].fill_(7.0)
+    inp, out = m.make_args(d, o)
+    s = torch.cuda.current_stream().cuda_stream
+    assert m.lib.qmpc_solve(m.h, 0, C.byref(inp), C.byref(out), C.c_void_p(s)) == 0
+    torch.cuda.synchronize()
+    assert (o["grf"] == 7.0).all()
+    assert m.lib.qmpc_solve(m.h, 9, C.byref(inp), C.byref(out), C.c_void_p(s)) == 1      # > max_batch
+    assert m.lib.qmpc_solve(m.h, -1, C.byref(inp), C.byref(out), C.c_void_p(s)) == 1
+    bad = type(inp)()
+    C.memmove(C.byref(bad), C.byref(inp), C.sizeof(inp))
+    bad.traj = None
+    assert m.lib.qmpc_solve(m.h, 8, C.byref(bad), C.byref(out), C.c_void_p(s)) == 1       # missing array
+    bad2 = type(inp)()
+    C.memmove(C.byref(bad2), C.byref(inp), C.sizeof(inp))
+    bad2.weights_stride = 5
+    assert m.lib.qmpc_solve(m.h, 8, C.byref(bad2), C.byref(out), C.c_void_p(s)) == 1      # bad stride
+    torch.cuda.synchronize()
+    assert (o["grf"] == 7.0).all()
+    m.solve_async(8, inp, out)
+    torch.cuda.synchronize()
+    assert not (o["grf"] == 7.0).all()
