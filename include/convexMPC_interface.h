@@ -48,7 +48,11 @@ QMPC_C_LINKAGE void update_problem_data_floats(float* p, float* v, float* q, flo
 void update_x_drag(float x_drag);
 #endif
 
-/* status bits (QMPC_ST_* of qmpc.h) of the most recent solve; -1 = never solved */
+/* status bits (QMPC_ST_* of qmpc.h) of the most recent solve; -1 = never solved.
+ * QMPC_SHIM_ST_JCQP_IGNORED is set next to them while update_solver_settings' use_jcqp is
+ * non-zero: the reference would then run its approximate ADMM alternate
+ * (SolverMPC.cpp:407-421, terminate = 0.1); this library returns the exact minimiser. */
+#define QMPC_SHIM_ST_JCQP_IGNORED 256
 QMPC_C_LINKAGE int qmpc_shim_last_status(void);
 /* active-set iterations of the most recent solve */
 QMPC_C_LINKAGE int qmpc_shim_last_iters(void);

@@ -26,6 +26,18 @@
  *                   src/MPC_Ctrl/SolverMPC.cpp:545-557)
  *   status[B]       per-robot status bits (QMPC_ST_*), 0 = solved
  *   iters[B]        optional, active-set iterations used
+ * Every output row of every robot is written by every call: a robot that is not
+ * solved (QMPC_ST_WS_FULL, QMPC_ST_INFEASIBLE) reads zero forces -- never a previous
+ * call's values and never an abandoned, primal-infeasible iterate -- and in command
+ * mode its controller state is advanced like everybody else's.
+ *
+ * Streams: a handle owns device state (coefficient tables, size-class work lists and
+ * their counters) that ONE stream at a time orders.  Calls on the same stream need
+ * nothing; a call that arrives on a different stream than the handle's previous call
+ * is made to wait on the device (event + hipStreamWaitEvent, no host block) for that
+ * previous stream's work, and qmpc_setup waits for solves in flight before it rewrites
+ * the tables.  For independent batches in flight at the same time use one handle per
+ * stream.  A handle is not thread-safe: serialise calls per handle.
  */
 #ifndef QMPC_H
 #define QMPC_H
@@ -133,8 +145,10 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 int qmpc_solve(qmpc_handle h, int batch, const qmpc_inputs* in,
                const qmpc_outputs* out, void* stream);
 
-/* Same with HOST pointers: copies in, solves, copies out, synchronises.
- * This is what the single-robot reference shim uses. */
+/* Same with HOST pointers; returns when the results are in the caller's arrays.  The record is
+ * gathered into one pinned, device-visible block: up to 64 robots the kernel reads and writes that
+ * block in place over PCIe (no copy commands -- one launch, one event wait: the latency path of the
+ * single-robot reference shim); larger batches use one H2D and one D2H copy. */
 int qmpc_solve_host(qmpc_handle h, int batch, const qmpc_inputs* in,
                     const qmpc_outputs* out);
 
@@ -144,6 +158,11 @@ int qmpc_solve_host(qmpc_handle h, int batch, const qmpc_inputs* in,
  * entries beyond n_r are padding).  Pass NULLs to switch off. */
 int qmpc_set_debug(qmpc_handle h, double* H_dev, double* g_dev);
 int qmpc_debug_ld(qmpc_handle h);
+/* Test hook: DEVICE buffer aux[B][8] receiving, per robot, the float transcendentals exactly as
+ * the kernel evaluated them -- cos(yaw), sin(yaw) (RobotState.cpp:30-35) and roll, pitch, yaw of
+ * quat_to_rpy (SolverMPC.cpp:257-267) -- so that a test can separate "same libm bits" from
+ * "same algebra" when it compares the assembled QP with an fp64 model.  NULL = off. */
+int qmpc_set_debug_aux(qmpc_handle h, double* aux_dev);
 /* Profiling hook: DEVICE buffer clk[B][16] receiving shader-clock stamps at
  * the kernel's phase boundaries (NULL = off). */
 int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);

@@ -28,9 +28,9 @@ def quat_to_rpy(q):
     return roll, pitch, yaw
 
 
-def ct_mats(r, yaw, x_drag, mass=9.0, ibody=(.07, .26, .242)):
+def ct_mats(r, yaw, x_drag, mass=9.0, ibody=(.07, .26, .242), trig=None):
     yaw = np.float64(yaw)
-    c, s = np.cos(yaw), np.sin(yaw)
+    c, s = (np.cos(yaw), np.sin(yaw)) if trig is None else (np.float64(trig[0]), np.float64(trig[1]))
     Ry = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
     Ib = np.diag(np.array(ibody, np.float32).astype(np.float64))
     Iinv = np.linalg.inv(Ry @ Ib @ Ry.T)
@@ -64,15 +64,24 @@ def coef_tables(h, dt):
     return coef, C
 
 
-def assemble(b, i):
-    """(H[12h,12h], g[12h]) in fp64 from instance i of batch dict b."""
+_TABLES = {}
+
+
+def assemble(b, i, trig=None, rpy=None):
+    """(H[12h,12h], g[12h]) in fp64 from instance i of batch dict b.
+    trig = (cos yaw, sin yaw) and rpy = (roll, pitch, yaw) override the fp64
+    transcendentals with externally evaluated ones (the reference and the GPU
+    evaluate them in float: RobotState.cpp:30-35, SolverMPC.cpp:257-267), so that a
+    comparison can pin the ALGEBRA to ~1e-13 independently of libm bits."""
     h = b["horizon"]
     dt = np.float64(np.float32(b["dt"]))
-    A, B = ct_mats(b["r"][i], b["yaw"][i], np.float64(b["x_drag"][i]))
+    A, B = ct_mats(b["r"][i], b["yaw"][i], np.float64(b["x_drag"][i]), trig=trig)
     Bp = [B, A @ B, A @ A @ B]
     W = np.zeros(13)
     W[:12] = b["weights"][i].astype(np.float64)
-    coef, C = coef_tables(h, dt)
+    if (h, dt) not in _TABLES:
+        _TABLES[(h, dt)] = coef_tables(h, dt)
+    coef, C = _TABLES[(h, dt)]
     n = 12 * h
     H = np.zeros((n, n))
     for p in range(3):
@@ -80,7 +89,7 @@ def assemble(b, i):
             E = Bp[p].T @ (W[:, None] * Bp[q])
             H += np.kron(C[p][q], E)
     H = 2 * (H + np.float64(b["alpha"][i]) * np.eye(n))
-    roll, pitch, yaw = quat_to_rpy(b["q"][i])
+    roll, pitch, yaw = quat_to_rpy(b["q"][i]) if rpy is None else [np.float64(v) for v in rpy]
     x0 = np.concatenate([[roll, pitch, yaw], b["p"][i], b["w"][i], b["v"][i],
                          [np.float64(np.float32(-9.8))]]).astype(np.float64)
     Ax, AAx = A @ x0, A @ A @ x0

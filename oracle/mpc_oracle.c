@@ -153,6 +153,52 @@ void oracle_c2d(const float* A, const float* B, float dt, float* Adt,
   }
 }
 
+
+/* ---- evaluation order of the float condensation (SolverMPC.cpp:395, :399).
+ * The reference writes qH = 2*(B_qp^T * S * B_qp + alpha*I) and leaves the
+ * order of the float operations to Eigen (un-vendored, unpinned): which
+ * product is formed first, how the length-13h inner sums are blocked into SIMD
+ * partial sums, and whether multiply-adds are fused all depend on the Eigen
+ * version and the compiler flags.  Mode 0 is the restatement's default; the
+ * other modes are equally legitimate evaluations of the same expression and
+ * are used ONLY to measure the reference pipeline's own float noise floor.
+ *   0  B^T (S B), sequential sum over k               (default)
+ *   1  (B^T S) B, sequential sum over k     -- left-to-right as written
+ *   2  B^T (S B), 4 interleaved partial sums  (SSE packet reduction)
+ *   3  B^T (S B), 8 interleaved partial sums  (AVX)
+ *   4  B^T (S B), sequential, fused multiply-add (-mfma builds)
+ *   5  (B^T S) B, 16 interleaved partial sums, fused (AVX-512 + fma)        */
+static int g_accum_mode = 0;
+void oracle_set_accum_mode(int mode) { g_accum_mode = mode; }
+int oracle_get_accum_mode(void) { return g_accum_mode; }
+
+/* sum_k a[k*sa] * s[k] * b[k*sb] in the selected order */
+static float accum_dot(const float* a, int sa, const float* b, int sb,
+                       const float* s, int len) {
+  const int mode = g_accum_mode;
+  const int lanes = (mode == 2) ? 4 : (mode == 3 ? 8 : (mode == 5 ? 16 : 1));
+  const int left = (mode == 1 || mode == 5), fused = (mode == 4 || mode == 5);
+  float part[16];
+  for (int l = 0; l < lanes; l++) part[l] = 0.f;
+  for (int k = 0; k < len; k++) {
+    const float av = a[(size_t)k * sa], bv = b[(size_t)k * sb];
+    float x, y;
+    if (left) {
+      x = av * s[k];
+      y = bv;
+    } else {
+      x = av;
+      y = s[k] * bv;
+    }
+    float* p = &part[k % lanes];
+    *p = fused ? fmaf(x, y, *p) : (*p + x * y);
+  }
+  /* pairwise reduction of the partial sums, like a SIMD horizontal add */
+  for (int w = lanes / 2; w >= 1; w /= 2)
+    for (int l = 0; l < w; l++) part[l] = part[l] + part[l + w];
+  return part[0];
+}
+
 /* SolverMPC.cpp:298-399, :423-429 */
 void oracle_assemble(const oracle_update_t* u, const oracle_setup_t* s,
                      double* H, double* g, double* Acon, double* lb,
@@ -212,7 +258,7 @@ void oracle_assemble(const oracle_update_t* u, const oracle_setup_t* s,
   for (int i = 0; i < ns; i++)
     for (int j = 0; j < n; j++)
       SB[(size_t)i * n + j] = Sd[i] * B_qp[(size_t)i * n + j];
-  {
+  if (g_accum_mode == 0) {
     /* k-outer order: per element the same sequential sum over k, unit-stride
      * inner loop (see matmul_f). */
     float* Hf = (float*)calloc((size_t)n * n, sizeof(float));
@@ -232,17 +278,30 @@ void oracle_assemble(const oracle_update_t* u, const oracle_setup_t* s,
         H[(size_t)i * n + j] = (double)(2.f * acc); /* :423 matrix_to_real */
       }
     free(Hf);
+  } else {
+    /* alternative evaluation orders of the same float expression (noise-floor
+     * measurement, tests/golden/make_noise_floor.py) */
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        float acc = accum_dot(B_qp + i, n, B_qp + j, n, Sd, ns);
+        if (i == j) acc += u->alpha;
+        H[(size_t)i * n + j] = (double)(2.f * acc);
+      }
   }
   /* :399  qg = 2 B^T S (A_qp x0 - X_d) */
   float* t = (float*)malloc(sizeof(float) * ns);
   for (int i = 0; i < ns; i++) {
     float acc = 0.f;
     for (int k = 0; k < 13; k++) acc += A_qp[i * 13 + k] * x0[k];
-    t[i] = Sd[i] * (acc - X_d[i]);
+    t[i] = (acc - X_d[i]);
+    if (g_accum_mode == 0) t[i] = Sd[i] * t[i];
   }
   for (int j = 0; j < n; j++) {
     float acc = 0.f;
-    for (int k = 0; k < ns; k++) acc += B_qp[(size_t)k * n + j] * t[k];
+    if (g_accum_mode == 0)
+      for (int k = 0; k < ns; k++) acc += B_qp[(size_t)k * n + j] * t[k];
+    else
+      acc = accum_dot(B_qp + j, n, t, 1, Sd, ns);
     g[j] = (double)(2.f * acc);
   }
 

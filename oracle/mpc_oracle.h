@@ -84,6 +84,12 @@ void oracle_assemble(const oracle_update_t* u, const oracle_setup_t* s,
                      double* H, double* g, double* Acon, double* lb,
                      double* ub, float* x0_out);
 
+/* Evaluation order of the float condensation (see mpc_oracle.c): 0 = default
+ * restatement; 1..5 = alternative, equally legitimate orders, used only by
+ * tests/golden/make_noise_floor.py to measure the reference's own fp32 noise. */
+void oracle_set_accum_mode(int mode);
+int oracle_get_accum_mode(void);
+
 /* Swing elimination, SolverMPC.cpp:441-525.  Returns new_vars; writes
  * new_cons, var_elim[n] flags and the gathered reduced problem. */
 int oracle_reduce(int n, int m, const double* H, const double* g,

@@ -13,6 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
+ABI_VERSION = 5              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_NONFINITE = 32
 ST_ERROR_MASK = 15 | 32
@@ -20,7 +21,8 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_setup", "qmpc_set_robot", "qmpc_settings", "qmpc_solve",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
-           "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance"]
+           "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
+           "qmpc_set_debug_aux"]
 
 # qmpc_command fields (include/qmpc.h), in declaration order
 CMD_F32 = ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot",
@@ -78,6 +80,7 @@ def load_library():
                                         C.POINTER(Outputs)]
         lib.qmpc_set_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
+        lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_min_stance.argtypes = [C.c_void_p, C.c_int]
@@ -299,6 +302,15 @@ class BatchedConvexMPC:
         self._dbg = (H, g)
         return H, g, ld
 
+    def debug_aux(self, batch):
+        """Enable the dump of the kernel's float transcendentals; returns the [batch,8] tensor
+        (cos yaw, sin yaw, roll, pitch, yaw)."""
+        t = self.torch
+        aux = t.zeros((batch, 8), dtype=t.float64, device=self.device)
+        self._check(self.lib.qmpc_set_debug_aux(self.h, aux.data_ptr()), "qmpc_set_debug_aux")
+        self._dbg_aux = aux
+        return aux
+
     def debug_clock(self, batch):
         """Enable per-phase shader-clock stamps; returns the [batch,16] tensor."""
         t = self.torch
@@ -310,4 +322,6 @@ class BatchedConvexMPC:
     def debug_off(self):
         self.lib.qmpc_set_debug_clock(self.h, None)
         self.lib.qmpc_set_debug(self.h, None, None)
+        self.lib.qmpc_set_debug_aux(self.h, None)
         self._dbg = None
+        self._dbg_aux = None

@@ -16,6 +16,7 @@ struct ShimState {
   bool has_solved = false;     // convexMPC_interface.cpp:81
   float x_drag = 0.f;          // update.x_drag
   int max_iter = 1000;
+  double use_jcqp = 0.0;       // update.use_jcqp (convexMPC_interface.cpp:118)
   std::vector<double> q_soln;  // SolverMPC.cpp:45
   int status = -1, iters = 0;
 } g;
@@ -54,7 +55,10 @@ void solve_floats(const float* p, const float* v, const float* q, const float* w
     std::fprintf(stderr, "[qmpc shim] solve failed rc=%d %s\n", rc, qmpc_last_error(g.h));
     return;
   }
-  g.status = st;
+  // use_jcqp in {1, 2} asks the reference for its ADMM alternate (SolverMPC.cpp:407-421), an
+  // approximate solve that stops at residual 0.1.  This library always returns the exact minimiser
+  // (what qpOASES returns, and what that ADMM converges to); the request is reported, not dropped
+  g.status = st | (g.use_jcqp != 0.0 ? QMPC_SHIM_ST_JCQP_IGNORED : 0);
   g.iters = it;
   if (st & QMPC_ST_ERROR_MASK) std::printf("failed to solve! (status bits %d)\n", st);  // SolverMPC.cpp:541
   g.has_solved = true;
@@ -77,7 +81,8 @@ void setup_problem(double dt, int horizon, double mu, double f_max) {
   qmpc_settings(g.h, g.max_iter, 1e-9);
 }
 
-void update_solver_settings(int max_iter, double, double, double, double, double) {
+void update_solver_settings(int max_iter, double, double, double, double, double use_jcqp) {
+  g.use_jcqp = use_jcqp;
   // the reference's active path caps qpOASES at nWSR = 100 regardless of this
   // value (SolverMPC.cpp:435); max_iter (10000 in the caller) bounds ours.
   g.max_iter = max_iter > 0 ? max_iter : 1000;

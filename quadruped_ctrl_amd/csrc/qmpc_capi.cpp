@@ -40,10 +40,23 @@ struct qmpc_ctx {
   int min_stance = 0;          // ... and lower bound (0 = unknown)
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
+  double* dbg_aux = nullptr;
   long long* dbg_clk = nullptr;
   // staging for qmpc_solve_host
   void* d_stage = nullptr;
   size_t stage_bytes = 0;
+  // the handle's device state (tables, work lists, counters) is ordered by ONE stream at a
+  // time: a call that arrives on a different stream is made to wait for the previous one
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
+  hipEvent_t order_ev = nullptr;
+  // host-pointer entry point: its own stream, one pinned (device-visible) staging block
+  hipStream_t host_stream = nullptr;
+  hipEvent_t host_ev = nullptr;
+  void* h_pin = nullptr;
+  size_t pin_bytes = 0;
+  double tab_dt = -1.0;  // (dt, horizon) the tables in d_tables were built for
+  int tab_h = -1;
   std::string err;
 };
 
@@ -69,11 +82,24 @@ int fail(qmpc_ctx* c, hipError_t e, const char* what) {
     if (e__ != hipSuccess) return fail(ctx, e__, #call); \
   } while (0)
 
+// One stream at a time orders the handle's device state.  A call on a different stream than the
+// previous one waits (on the device, no host block) for everything the previous stream was given.
+int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
+  if (c->has_last && c->last_stream != stream) {
+    if (!c->order_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->order_ev, c->last_stream));
+    HIP_TRY(c, hipStreamWaitEvent(stream, c->order_ev, 0));
+  }
+  c->last_stream = stream;
+  c->has_last = true;
+  return QMPC_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 4; }
+int qmpc_abi_version(void) { return 5; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -110,6 +136,10 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_lists) hipFree(h->d_lists);
     if (h->d_counts) hipFree(h->d_counts);
     if (h->d_stage) hipFree(h->d_stage);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    if (h->order_ev) hipEventDestroy(h->order_ev);
+    if (h->host_ev) hipEventDestroy(h->host_ev);
+    if (h->host_stream) hipStreamDestroy(h->host_stream);
   }
   delete h;
   return QMPC_OK;
@@ -124,6 +154,9 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   c->f_max = (double)(float)f_max;
   c->horizon = horizon;
   const int h = horizon;
+  // the tables depend on (dt, horizon) only: the reference's caller repeats setup_problem with the
+  // same values before every solve (ConvexMPCLocomotion.cpp:630), which costs nothing here
+  if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h) return QMPC_OK;
   // coefficient tables (see qmpc_device.h); A_ct^3 = 0 makes
   // Adt^d Bdt = dt B + c_d A B + e_d A^2 B exact.
   std::vector<double> t(3 * h + 9 * h * h);
@@ -145,7 +178,11 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
           ctab[((p * 3 + q) * h + i) * h + j] = s;
         }
   DeviceGuard g(c->device);
+  // solves still in flight read the old tables: wait for the stream that orders this handle
+  if (c->has_last) HIP_TRY(c, hipStreamSynchronize(c->last_stream));
   HIP_TRY(c, hipMemcpy(c->d_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+  c->tab_dt = c->dt;
+  c->tab_h = h;
   c->is_setup = true;
   return QMPC_OK;
 }
@@ -183,6 +220,12 @@ int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_H = H_dev;
   c->dbg_g = g_dev;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug_aux(qmpc_handle c, double* aux_dev) {
+  if (!c) return QMPC_ERR_ARG;
+  c->dbg_aux = aux_dev;
   return QMPC_OK;
 }
 
@@ -226,6 +269,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   hipStream_t stream = (hipStream_t)stream_;
   DeviceGuard g(c->device);
   const int h = c->horizon;
+  if (const int rc = order_after_previous(c, stream)) return rc;
 
   QmpcParams P;
   std::memset(&P, 0, sizeof(P));
@@ -265,6 +309,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.tol = c->tol;
   P.dbg_H = c->dbg_H;
   P.dbg_g = c->dbg_g;
+  P.dbg_aux = c->dbg_aux;
   P.dbg_clk = c->dbg_clk;
 
   // size classes by padded rows: 64 (kernel class 1), 96 (class 4), 128 (class 2), 192 (class 3);
@@ -329,6 +374,7 @@ int qmpc_pack(qmpc_handle c, int batch, const qmpc_command* cmd, const qmpc_reco
   if (!rec->p || !rec->v || !rec->q || !rec->w || !rec->r || !rec->yaw || !rec->traj || !rec->gait || !rec->x_drag)
     return QMPC_ERR_ARG;
   DeviceGuard g(c->device);
+  if (const int rc = order_after_previous(c, (hipStream_t)stream_)) return rc;
   HIP_TRY(c, qmpc_launch_pack(cmd, rec, batch, c->horizon, (float)c->dt, (hipStream_t)stream_));
   return QMPC_OK;
 }
@@ -338,6 +384,7 @@ int qmpc_forces_to_body(qmpc_handle c, int batch, const float* r_body, const flo
   if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
   if (batch == 0) return QMPC_OK;
   DeviceGuard g(c->device);
+  if (const int rc = order_after_previous(c, (hipStream_t)stream_)) return rc;
   HIP_TRY(c, qmpc_launch_f2b(r_body, grf, f_ff, batch, (hipStream_t)stream_));
   return QMPC_OK;
 }
@@ -351,11 +398,16 @@ int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_
     return QMPC_ERR_ARG;
   DeviceGuard g(c->device);
   const size_t B = (size_t)batch, h = (size_t)c->horizon;
-  // carve one staging allocation (256-byte aligned pieces)
+  // ONE pinned host block holds the whole record and the results:  [ inputs | outputs ].
+  //   * small batches (the single-robot shim): the kernel reads and writes the pinned block in
+  //     place over PCIe (hipHostMalloc memory is device-visible and coherent) -- no copy
+  //     commands at all, one launch and one event wait;
+  //   * large batches: ONE H2D copy of the input part into a device mirror, ONE D2H copy of the
+  //     output part back (PCIe bandwidth, not latency, matters there).
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     const size_t o = off;
-    off += (bytes + 255) & ~(size_t)255;
+    off += (bytes + 63) & ~(size_t)63;
     return o;
   };
   const size_t wN = in->weights_stride ? 12 * B : 12, aN = in->alpha_stride ? B : 1,
@@ -363,24 +415,47 @@ int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_
   const size_t o_p = carve(4 * 3 * B), o_v = carve(4 * 3 * B), o_q = carve(4 * 4 * B),
                o_w = carve(4 * 3 * B), o_r = carve(4 * 12 * B), o_yaw = carve(4 * B),
                o_traj = carve(4 * 12 * h * B), o_gait = carve(4 * h * B), o_wt = carve(4 * wN),
-               o_al = carve(4 * aN), o_xd = carve(4 * xN), o_grf = carve(4 * 12 * B),
-               o_soln = carve(out->soln ? 8 * 12 * h * B : 0), o_st = carve(4 * B),
+               o_al = carve(4 * aN), o_xd = carve(4 * xN);
+  const size_t in_bytes = (off + 255) & ~(size_t)255;
+  off = in_bytes;
+  const size_t o_grf = carve(4 * 12 * B), o_soln = carve(out->soln ? 8 * 12 * h * B : 0), o_st = carve(4 * B),
                o_it = carve(out->iters ? 4 * B : 0);
-  if (off > c->stage_bytes) {
+  const size_t total = off, out_bytes = total - in_bytes;
+  if (total > c->pin_bytes) {
+    if (c->h_pin) hipHostFree(c->h_pin);
+    c->h_pin = nullptr;
+    c->pin_bytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_pin, total, hipHostMallocDefault));
+    c->pin_bytes = total;
+  }
+  if (!c->host_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking));
+  if (!c->host_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->host_ev, hipEventDisableTiming));
+  const bool in_place = batch <= 64;
+  if (!in_place && total > c->stage_bytes) {
     if (c->d_stage) hipFree(c->d_stage);
     c->d_stage = nullptr;
     c->stage_bytes = 0;
-    HIP_TRY(c, hipMalloc(&c->d_stage, off));
-    c->stage_bytes = off;
+    HIP_TRY(c, hipMalloc(&c->d_stage, total));
+    c->stage_bytes = total;
   }
-  char* base = (char*)c->d_stage;
-  hipStream_t s = nullptr;
-#define H2D(o, src, bytes) HIP_TRY(c, hipMemcpyAsync(base + (o), (src), (bytes), hipMemcpyHostToDevice, s))
-  H2D(o_p, in->p, 4 * 3 * B); H2D(o_v, in->v, 4 * 3 * B); H2D(o_q, in->q, 4 * 4 * B);
-  H2D(o_w, in->w, 4 * 3 * B); H2D(o_r, in->r, 4 * 12 * B); H2D(o_yaw, in->yaw, 4 * B);
-  H2D(o_traj, in->traj, 4 * 12 * h * B); H2D(o_gait, in->gait, 4 * h * B);
-  H2D(o_wt, in->weights, 4 * wN); H2D(o_al, in->alpha, 4 * aN); H2D(o_xd, in->x_drag, 4 * xN);
-#undef H2D
+  char* hb = (char*)c->h_pin;
+  std::memcpy(hb + o_p, in->p, 4 * 3 * B);
+  std::memcpy(hb + o_v, in->v, 4 * 3 * B);
+  std::memcpy(hb + o_q, in->q, 4 * 4 * B);
+  std::memcpy(hb + o_w, in->w, 4 * 3 * B);
+  std::memcpy(hb + o_r, in->r, 4 * 12 * B);
+  std::memcpy(hb + o_yaw, in->yaw, 4 * B);
+  std::memcpy(hb + o_traj, in->traj, 4 * 12 * h * B);
+  std::memcpy(hb + o_gait, in->gait, 4 * h * B);
+  std::memcpy(hb + o_wt, in->weights, 4 * wN);
+  std::memcpy(hb + o_al, in->alpha, 4 * aN);
+  std::memcpy(hb + o_xd, in->x_drag, 4 * xN);
+  hipStream_t s = c->host_stream;
+  char* base = in_place ? hb : (char*)c->d_stage;
+  if (!in_place) {
+    if (const int rc = order_after_previous(c, s)) return rc;  // the mirror may still be read by an earlier call
+    HIP_TRY(c, hipMemcpyAsync(base, hb, in_bytes, hipMemcpyHostToDevice, s));
+  }
   qmpc_inputs din = *in;
   din.p = (const float*)(base + o_p); din.v = (const float*)(base + o_v);
   din.q = (const float*)(base + o_q); din.w = (const float*)(base + o_w);
@@ -395,13 +470,19 @@ int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_
   dout.iters = out->iters ? (int32_t*)(base + o_it) : nullptr;
   const int rc = qmpc_solve(c, batch, &din, &dout, s);
   if (rc != QMPC_OK) return rc;
-#define D2H(dst, o, bytes) HIP_TRY(c, hipMemcpyAsync((dst), base + (o), (bytes), hipMemcpyDeviceToHost, s))
-  D2H(out->grf, o_grf, 4 * 12 * B);
-  if (out->soln) D2H(out->soln, o_soln, 8 * 12 * h * B);
-  D2H(out->status, o_st, 4 * B);
-  if (out->iters) D2H(out->iters, o_it, 4 * B);
-#undef D2H
-  HIP_TRY(c, hipStreamSynchronize(s));
+  if (!in_place) HIP_TRY(c, hipMemcpyAsync(hb + in_bytes, base + in_bytes, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipEventRecord(c->host_ev, s));
+  // latency path: poll the event for a short while before handing the thread to the OS
+  {
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 20000 && q == hipErrorNotReady; ++spin) q = hipEventQuery(c->host_ev);
+    if (q == hipErrorNotReady) q = hipEventSynchronize(c->host_ev);
+    if (q != hipSuccess) return fail(c, q, "qmpc_solve_host wait");
+  }
+  std::memcpy(out->grf, hb + o_grf, 4 * 12 * B);
+  if (out->soln) std::memcpy(out->soln, hb + o_soln, 8 * 12 * h * B);
+  std::memcpy(out->status, hb + o_st, 4 * B);
+  if (out->iters) std::memcpy(out->iters, hb + o_it, 4 * B);
   return QMPC_OK;
 }
 

@@ -81,6 +81,7 @@ struct QmpcParams {
   // debug dump (nullptr = off)
   double* dbg_H;
   double* dbg_g;
+  double* dbg_aux;     // [batch][8]: cos/sin(yaw), roll, pitch, yaw as the kernel evaluated them (float transcendentals)
   long long* dbg_clk;  // [batch][16] shader-clock stamps per phase
 };
 

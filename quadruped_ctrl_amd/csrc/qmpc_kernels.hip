@@ -469,6 +469,10 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     float syf, cyf;
     sincosf(g_yaw, &syf, &cyf);
     const double cy = cyf, sy = syf;
+    if (PK.dbg_aux && tid == 0) {  // test hook: the float transcendentals as evaluated here
+      PK.dbg_aux[(size_t)rid * 8 + 0] = cy;
+      PK.dbg_aux[(size_t)rid * 8 + 1] = sy;
+    }
     if (tid < 72) {
       // M_b = I_w^-1 [r_b]x with I_w^-1 = R diag(1/I) R^T (closed form of
       // I_world.inverse(), SolverMPC.cpp:319,:247), N_b = R^T M_b.
@@ -515,6 +519,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         }
         const double o0 = g_w[0], o1 = g_w[1], o2 = g_w[2];
         const double rate = (row == 0) ? (cy * o0 + sy * o1) : (row == 1 ? (-sy * o0 + cy * o1) : o2);
+        if (PK.dbg_aux && ek == 0) PK.dbg_aux[(size_t)rid * 8 + 2 + row] = (double)ang;  // roll, pitch, yaw as evaluated
         val = (double)ang + rate * t;  // Theta' = R_yaw^T omega
       } else if (row < 6) {
         val = (double)g_p + (double)(row == 3 ? g_v[0] : (row == 4 ? g_v[1] : g_v[2])) * t;
@@ -572,12 +577,21 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         if (P.iters) P.iters[rid] = 0;
         if (cmdm) cmd_finish_state();
       }
-    } else if (tid == 0) {
-      if (P.next_list) {
+    } else if (P.next_list) {
+      if (tid == 0) {
         const int slot = atomicAdd(P.next_count, 1);
         P.next_list[slot] = rid;
-      } else {
+      }
+    } else {
+      // larger than the caller's size hint allows and no class left to take it: reported, with
+      // every output of the robot defined (zero forces, never a previous call's values) and
+      // the controller state advanced like everybody else's
+      if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
+      if (cmdm && P.f_ff && tid < 12) P.f_ff[(size_t)rid * 12 + tid] = 0.f;
+      if (tid == 0) {
         P.status[rid] = QMPC_DEV_ST_WS_FULL;
+        if (P.iters) P.iters[rid] = 0;
+        if (cmdm) cmd_finish_state();
       }
     }
     __syncthreads();
@@ -1278,12 +1292,15 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       if (!retry) {
         // outputs: get_solution(0..11) = forces of the four feet at horizon step 0
         // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685)
+        // an iterate the method abandoned (constraints found inconsistent) is not a solution:
+        // the robot is reported and its forces read zero rather than a primal-infeasible point
+        const bool dead = (status & (QMPC_DEV_ST_INFEASIBLE | QMPC_DEV_ST_WS_FULL)) != 0;
         if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < RE; ++q) {
           const int j = lane + 64 * q;
-          if (j < n) {
+          if (j < n && !dead) {
             const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
             if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xv[q];
             if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
@@ -1307,7 +1324,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
           for (int q = 0; q < RE; ++q) {
             const int j = lane + 64 * q;
-            if (j < n && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
+            if (j < n && !dead && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
           }
           __builtin_amdgcn_wave_barrier();
           if (lane < 12) cmd_finish_forces(fb, lane);
@@ -1671,12 +1688,15 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     // get_solution(0..11): forces of the four feet at horizon step 0
     // (convexMPC_interface.cpp:175-180, ConvexMPCLocomotion.cpp:672-685);
     // feet in swing at step 0 read 0.
+    // (an abandoned iterate -- working-set storage exhausted, constraints inconsistent -- is
+    //  not a solution: the robot is reported and its forces read zero)
+    const bool dead = (status & (QMPC_DEV_ST_INFEASIBLE | QMPC_DEV_ST_WS_FULL)) != 0;
     if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < RE; ++q) {
       const int j = lane + 64 * q;
-      if (j < n) {
+      if (j < n && !dead) {
         const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
         if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xv[q];
         if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
@@ -1700,7 +1720,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
       for (int q = 0; q < RE; ++q) {
         const int j = lane + 64 * q;
-        if (j < n && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
+        if (j < n && !dead && S.sidx[j / 3] < 4) fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < 12) cmd_finish_forces(fb, lane);

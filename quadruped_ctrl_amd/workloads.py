@@ -125,6 +125,16 @@ def make_standing(batch, horizon=10, seed=99):
     return _finish(d, batch, horizon, np.ones((batch, 4 * horizon), np.uint8))
 
 
+def make_trot(batch, horizon, seed=55):
+    """Trot at an arbitrary even horizon (offsets 0, h/2, h/2, 0; durations h/2) -- the
+    reference's own trot has 14 / 16 segments (ConvexMPCLocomotion.cpp:25,27)."""
+    rng = np.random.default_rng(SEED0 + seed + horizon)
+    d = _states(rng, batch, horizon)
+    hh = horizon // 2
+    table = {"trot": ((0, hh, hh, 0), (hh,) * 4)}
+    return _finish(d, batch, horizon, _gait_tables(rng, batch, horizon, ["trot"], table))
+
+
 def shard(d, rank, world):
     """Contiguous batch slice [rank*ceil(B/world), ...) -- SURVEY.md 8(e)."""
     B = d["batch"]

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(binding.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qmpc_abi_version() == 4
+    assert lib.qmpc_abi_version() == binding.ABI_VERSION
 
 
 def test_shim_exports_reference_symbols():

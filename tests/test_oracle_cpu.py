@@ -20,6 +20,8 @@ from oracle import kron_model as K
 from oracle import oracle as O
 from quadruped_ctrl_amd import workloads as W
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
               if not os.path.basename(p).startswith("pack_"))
 needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (reference qpOASES build) absent")
@@ -164,3 +166,29 @@ def test_all_swing_returns_zeros():
     b["gait"][:] = 0
     q, nwsr, rc = O.solve_batch(b)
     assert np.all(q == 0) and np.all(rc == 0)
+
+
+def test_noise_floor_module_and_fixture():
+    """The fp32 noise floor of the reference pipeline (oracle/noise_floor.py): the six float
+    evaluation orders are genuinely different roundings of ONE expression (tiny but non-zero
+    spread, all within float noise of the fp64 assembly), and the committed fixture matches a
+    live re-measurement on the golden inputs."""
+    import json
+    from oracle import noise_floor as NF
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cfg3_trot_h16.npz"))
+    b = {k: z[k] for k in z.files}
+    for k in ("batch", "horizon"):
+        b[k] = int(b[k])
+    for k in ("dt", "mu", "f_max"):
+        b[k] = float(b[k])
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "noise_floor.json")))["families"]["cfg3_trot_h16"]
+    for i in (0, 7):
+        v = NF.variants(b, i)
+        assert np.array_equal(v[0], b["q_soln"][i])             # mode 0 IS the golden pipeline
+        f = NF.robot_floor(b, i)
+        assert 0 < f["spread12"] < 2e-3 and 0 < f["fp64_12"] < 2e-3
+        assert abs(f["fp64_12"] - fix["per_robot_first_step"][i]) <= 2e-3 * f["fp64_12"] + 1e-12
+    # horizon-10 families sit below north_star's 1e-4 with margin; the long horizons do not
+    fam = json.load(open(os.path.join(ROOT, "tests", "golden", "noise_floor.json")))["families"]
+    assert fam["cfg1_trot_h10"]["fp64_to_float_first_step"]["max"] < 1e-4
+    assert fam["trot_h16_96"]["fp64_to_float_first_step"]["max"] > 1e-4
