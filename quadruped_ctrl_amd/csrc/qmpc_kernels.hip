@@ -478,8 +478,13 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       // I_world.inverse(), SolverMPC.cpp:319,:247), N_b = R^T M_b.
       const int b = mb, l = ml, ax = max_;
       const double ix = PK.inv_ibody[0], iy = PK.inv_ibody[1], iz = PK.inv_ibody[2];
-      const double I00 = cy * cy * ix + sy * sy * iy, I01 = cy * sy * (ix - iy),
-                   I11 = sy * sy * ix + cy * cy * iy;
+      // cy, sy are float evaluations, so cy^2 + sy^2 = 1 + e with |e| ~ 1e-7 and R is not exactly
+      // orthogonal: the exact inverse of R I_body R^T is the closed form divided by (1 + e)^2
+      // (1 - 2e + 3e^2 to 1e-20), which is what I_world.inverse() returns up to its own rounding
+      const double en = __builtin_fma(cy, cy, sy * sy) - 1.0;
+      const double isc = 1.0 - 2.0 * en + 3.0 * en * en;
+      const double I00 = (cy * cy * ix + sy * sy * iy) * isc, I01 = (cy * sy * (ix - iy)) * isc,
+                   I11 = (sy * sy * ix + cy * cy * iy) * isc;
       const double rx = g_r0, ry = g_r1, rz = g_r2;
       // column ax of [r]x  (cross_mat, SolverMPC.cpp:226-233)
       const double cm0 = (ax == 0) ? 0.0 : (ax == 1 ? -rz : ry);

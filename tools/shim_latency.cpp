@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
   const int cycles = argc > 2 ? std::atoi(argv[2]) : 2000;
   std::vector<double> us;
   double sink = 0;
+  int bad = 0;
   for (int it = 0; it < cycles + 50; ++it) {
     float* r = &rec[(size_t)(it % nrec) * nf];
     int* g = &gait[(size_t)(it % nrec) * 4 * h];
@@ -42,17 +43,14 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 12; ++k) sink += get_solution(k);
     const auto t1 = std::chrono::steady_clock::now();
     if (it >= 50) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
-    if (qmpc_shim_last_status() != 0) {
-      std::fprintf(stderr, "status %d\n", qmpc_shim_last_status());
-      return 1;
-    }
+    if (qmpc_shim_last_status() != 0) ++bad;
   }
   std::sort(us.begin(), us.end());
   double mean = 0;
   for (double v : us) mean += v;
   mean /= us.size();
   std::printf("{\"horizon\": %d, \"cycles\": %d, \"mean_us\": %.2f, \"median_us\": %.2f, \"p10_us\": %.2f, \"p99_us\": %.2f, "
-              "\"iters_last\": %d, \"sink\": %.3f}\n",
-              h, cycles, mean, us[us.size() / 2], us[us.size() / 10], us[us.size() * 99 / 100], qmpc_shim_last_iters(), sink);
+              "\"iters_last\": %d, \"status_nonzero\": %d, \"sink\": %.3f}\n",
+              h, cycles, mean, us[us.size() / 2], us[us.size() / 10], us[us.size() * 99 / 100], qmpc_shim_last_iters(), bad, sink);
   return 0;
 }

@@ -36,7 +36,7 @@ def main():
     out = []
     fams = [("trot_h10", W.make_config(1, batch=64)), ("trot_h14", W.make_trot(64, 14)),
             ("trot_h16", W.make_config(3, batch=64)), ("standing_h10", W.make_standing(64, 10)),
-            ("standing_h16", W.make_standing(32, 16))]
+            ("standing_h14", W.make_standing(32, 14)), ("standing_h16", W.make_standing(32, 16))]
     for name, b in fams:
         path = f"/tmp/shim_{name}.bin"
         write_records(b, path)
