@@ -1,26 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- convex-MPC QP solves/sec on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config C] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--config C | --workload standing --horizon H] [--batch B]
 
 One "step" = one pass of the whole hot path (state -> linearisation -> condensed
 QP -> exact QP solve -> first-step GRF) over one batch of synthetic robot states
 already resident in HBM.  Default workload is BASELINE.json configs[1]
 (batch=1024 robots, trot, horizon=10).  N>1 (launched by torch.distributed.run,
 one rank per GPU) shards independent robots across ranks with no data-path
-collective: every rank solves its own `batch` robots (weak scaling); the only
-RCCL traffic is the timing barrier/all-reduce.
+collective: every rank solves its own `batch` robots (weak scaling); RCCL carries
+the timing barrier / MAX and, with --gather, ONE all_gather_into_tensor of the
+48-byte result rows per step (consumers that need every force on
+every GPU).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      algorithmic fp64 flops (F_alg of SURVEY.md 8d) over the HIP-event-timed
-                average step duration vs the 78.6 TFLOP/s dense fp64 peak; roofline_hbm:
-                algorithmic HBM bytes (728 B/QP at h=10) vs 8 TB/s
-  cpu_baseline  the oracle pipeline (C restatement of the reference assembly +
-                the reference's own qpOASES, oracle/_ref) on one host core
+  roofline      bound "fp64_valu": the kernel issues vector fp64 (no MFMA; on MI355X the dense
+                fp64 MFMA peak equals the fp64 vector peak, 78.6 TFLOP/s).  `achieved` = the
+                ALGORITHMIC flops of SURVEY.md 8d (what the reference's dense formulation needs)
+                over the HIP-event kernel time; `executed_*` = what the kernel really issues, from
+                the SQ_INSTS_VALU_*_F64 counters of the last PMC run of THIS kernel source
+                (profiles/pmc_latest.json carries the source hash; stale -> null)
+  roofline_hbm  algorithmic HBM bytes (728 B/QP at h=10) vs 8 TB/s; traffic from PMC likewise
+  cpu_baseline  the oracle pipeline (C restatement of the reference assembly + the
+                reference's own qpOASES, oracle/_ref): one host core, and one worker
+                process per host core (core count + CPU model stated)
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,7 +40,16 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64 (half the 157.3 TF FP32 rate)
+FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64 (= dense FP64 MFMA peak)
+KERNEL_SOURCES = ["quadruped_ctrl_amd/csrc/qmpc_kernels.hip", "quadruped_ctrl_amd/csrc/qmpc_cmd.h",
+                  "quadruped_ctrl_amd/csrc/qmpc_device.h"]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def alg_bytes_per_qp(h):
@@ -47,8 +65,19 @@ def alg_flops_per_qp(h, nr_mean, k_mean):
     return f_cond + 2 * f_fact + k_mean * f_iter
 
 
-def cpu_baseline(b, budget_s=12.0):
-    """Reference-style CPU pipeline on ONE host core, bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(b, spec, budget_s=8.0, all_cores=True):
+    """Reference-style CPU pipeline, bounded sample: one host core in-process, then one worker
+    process per host core (oracle/cpu_worker.py)."""
     try:
         from oracle import oracle
         if not oracle.have_ref():
@@ -64,12 +93,27 @@ def cpu_baseline(b, budget_s=12.0):
         for _ in range(reps):
             oracle.solve_packed(arr, b)
         dt = time.perf_counter() - t0
-        return {"value": n * reps / dt, "unit": "QP solves/s", "cores": 1,
-                "kind": "port",
-                "sample": f"{reps}x first {n} robots of the workload; C restatement of "
-                          f"SolverMPC.cpp assembly (fp32 dense) + the reference's own "
-                          f"qpOASES 3.2.0 build (oracle/_ref), single thread, "
-                          f"{dt:.1f} s of CPU time"}
+        res = {"value": n * reps / dt, "unit": "QP solves/s", "cores": 1, "kind": "port",
+               "cpu_model": cpu_model(),
+               "sample": f"{reps}x first {n} robots of the workload; C restatement of "
+                         f"SolverMPC.cpp assembly (fp32 dense) + the reference's own "
+                         f"qpOASES 3.2.0 build (oracle/_ref), single thread, {dt:.1f} s of CPU time"}
+        if all_cores:
+            cores = os.cpu_count() or 1
+            wspec = dict(spec, batch=min(spec["batch"], 256))
+            env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+            procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", json.dumps(wspec), str(budget_s)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT, env=env)
+                     for _ in range(cores)]
+            outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
+            total = sum(o["solved"] for o in outs)
+            span = max(o["elapsed"] for o in outs)
+            res["all_cores"] = {"value": total / span, "unit": "QP solves/s", "cores": cores,
+                                "per_core": total / span / cores, "cpu_model": cpu_model(),
+                                "sample": f"{cores} worker processes (one per host core, the reference is "
+                                          f"single-threaded and non-reentrant), each looping over the first "
+                                          f"{wspec['batch']} robots for {budget_s:.0f} s"}
+        return res
     except Exception as e:  # baseline is reporting only; never fail the bench
         return {"value": None, "error": repr(e)}
 
@@ -80,11 +124,19 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index")
+    ap.add_argument("--workload", choices=["config", "standing", "trot"], default="config",
+                    help="'standing' = all four feet down for the whole horizon (the robot's default posture, the "
+                         "reference's Standing gait, ConvexMPCLocomotion.cpp:35: n_r = 12 h); 'trot' = trot at --horizon")
+    ap.add_argument("--horizon", type=int, default=10, help="for --workload standing / trot (reference: 10, 14, 16)")
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (override)")
     ap.add_argument("--settle", type=float, default=0.3,
                     help="seconds of untimed load before the W warmup steps (GPU clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="cpu_baseline on one core only")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream measurement")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: after every solve, all_gather_into_tensor the grf[shard][12] rows over RCCL so that "
+                         "every rank holds all forces (inside the timed region)")
     ap.add_argument("--caller-side", choices=["fused", "three-calls"], default=None,
                     help="time command -> record -> solve -> body-frame forces per step instead of the solve alone "
                          "(SURVEY row a12 on the GPU; not the headline configuration): 'fused' = one "
@@ -119,9 +171,20 @@ def main():
 
     # per-rank batch: the named config's batch on one GPU; rank r gets its own
     # independent robots (different seed stream via the config generator + rank)
-    cfg_batch = {0: 1, 1: 1024, 2: 4096, 3: 16384, 4: 65536}[args.config]
-    per_gpu = args.batch or (cfg_batch if args.config in (0, 1, 2) else cfg_batch // (4 if args.config == 3 else 8))
-    full = workloads.make_config(args.config, batch=per_gpu * world)
+    if args.workload == "config":
+        cfg_batch = {0: 1, 1: 1024, 2: 4096, 3: 16384, 4: 65536}[args.config]
+        per_gpu = args.batch or (cfg_batch if args.config in (0, 1, 2) else cfg_batch // (4 if args.config == 3 else 8))
+        full = workloads.make_config(args.config, batch=per_gpu * world)
+        spec = {"kind": "config", "config": args.config, "batch": per_gpu}
+        wname = f"BASELINE.json configs[{args.config}]"
+        wkey = f"config{args.config}"
+    else:
+        per_gpu = args.batch or 1024
+        mk = workloads.make_standing if args.workload == "standing" else workloads.make_trot
+        full = mk(per_gpu * world, args.horizon)
+        spec = {"kind": args.workload, "horizon": args.horizon, "batch": per_gpu}
+        wname = f"{args.workload} (all four feet in stance)" if args.workload == "standing" else "trot"
+        wkey = f"{args.workload}_h{args.horizon}"
     b = workloads.shard(full, rank, world)
     h = b["horizon"]
 
@@ -162,6 +225,16 @@ def main():
             mpc.pack_async(mpc.upload_command(cmd), rec, stream)
         mpc.solve_async = step_all
 
+    gathered = None
+    if args.gather and dist is not None:
+        gathered = torch.empty((world * per_gpu, 12), dtype=torch.float32, device=f"cuda:{dev}")
+
+    def one_step():
+        mpc.solve_async(per_gpu, inp, out, stream)
+        if gathered is not None:
+            # torch's NCCL(=RCCL) work is enqueued on its own stream and ordered after `stream`
+            dist.all_gather_into_tensor(gathered, o["grf"])
+
     def sync_all():
         if dist is not None:
             dist.barrier()
@@ -174,22 +247,26 @@ def main():
             mpc.solve_async(per_gpu, inp, out, stream)
         torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
-        mpc.solve_async(per_gpu, inp, out, stream)
+        one_step()
     sync_all()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        mpc.solve_async(per_gpu, inp, out, stream)
+        one_step()
     ev1.record(stream)
     sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     ev_ms = ev0.elapsed_time(ev1)           # HIP events on the launch stream
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=f"cuda:{dev}")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
 
     # ---- extra (not part of the contract fields): the same K steps with two independent
     # batches in flight on two HIP streams.  At batch 1024 a launch is exactly one round of
@@ -208,6 +285,7 @@ def main():
         o2 = mpc2.alloc_outputs(per_gpu, full=False, iters=True)
         inp2, out2 = mpc2.make_args(d, o2)            # same resident inputs, its own outputs
         ctx.append((mpc2, inp2, out2))
+        torch.cuda.synchronize(dev)
         for k in range(2 * max(args.warmup, 2)):
             m_, i_, o_ = ctx[k % 2]
             m_.solve_async(per_gpu, i_, o_, streams[k % 2])
@@ -229,6 +307,11 @@ def main():
     iters = o["iters"].cpu().numpy()
     nst = ((rec["gait"].cpu().numpy() if args.caller_side else b["gait"]) != 0).sum(1)
     n_fail = int(((status & 47) != 0).sum())   # QMPC_ST_ERROR_MASK
+    gather_ok = None
+    if gathered is not None:
+        torch.cuda.synchronize(dev)
+        mine = gathered[rank * per_gpu:(rank + 1) * per_gpu]
+        gather_ok = bool(torch.equal(mine, o["grf"]))
 
     if rank == 0:
         total_qp = per_gpu * world * args.steps
@@ -236,14 +319,29 @@ def main():
         step_ms_ev = ev_ms / args.steps
         abytes = alg_bytes_per_qp(h) * per_gpu
         ach = abytes / (step_ms_ev * 1e-3) / 1e9
-        traffic = None
+        # counters of the last PMC run (tools/pmc.sh -> tools/pmc_to_latest.py), valid only for the
+        # kernel source they were collected on
+        traffic = executed = None
+        pmc_note = "no PMC entry for this workload in profiles/pmc_latest.json"
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"config{args.config}", {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(pmc)).get(wkey)
+                if ent and ent.get("batch") == per_gpu:
+                    if ent.get("kernel_source_sha") == kernel_source_hash():
+                        traffic = ent.get("hbm_bytes_per_launch")
+                        executed = ent.get("fp64_flops_per_launch")
+                        pmc_note = f"PMC counters from {ent.get('profile')} (same kernel source)"
+                    else:
+                        pmc_note = "profiles/pmc_latest.json was collected on a different kernel source: dropped"
             except Exception:
-                traffic = None
-        flops = alg_flops_per_qp(h, 3.0 * nst.mean(), float(iters.mean())) * per_gpu
+                pass
+        nr_mean = 3.0 * nst.mean()
+        flops = alg_flops_per_qp(h, nr_mean, float(iters.mean())) * per_gpu
+        nr_max = 3 * int(nst.max())
+        kclass = 1 if nr_max <= 64 else (4 if nr_max <= 96 else (2 if nr_max <= 128 else 3))
+        kname = f"qmpc_solve_kernel<{kclass}, {'true' if args.caller_side == 'fused' else 'false'}>"
+        t_s = step_ms_ev * 1e-3
         res = {
             "metric": "convex-MPC QP solves/sec (horizon=%d, 4-leg)" % h,
             "value": value, "unit": "QP solves/s", "n_gpus": world,
@@ -252,32 +350,41 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"caller-side pipeline ({args.caller_side}: command -> record -> solve -> body-frame forces), " if args.caller_side else "") +
-                                   f"BASELINE.json configs[{args.config}]: batch={per_gpu} robots/GPU, "
-                                   f"horizon={h}, mean reduced QP size {3.0 * nst.mean():.1f} vars",
+                                   f"{wname}: batch={per_gpu} robots/GPU, "
+                                   f"horizon={h}, mean reduced QP size {nr_mean:.1f} vars",
                        "batch_per_gpu": per_gpu, "horizon": h, "sharding": f"independent robots x{world}",
-                       "mean_active_set_iters": float(iters.mean()), "failed": n_fail,
-                       "max_stance_hint": (0 if args.no_hint else max_stance)},
-            # The path is compute-shaped, not HBM-shaped: the binding roof is
-            # the fp64 rate.  On MI355X the dense fp64 MFMA peak equals the fp64 vector peak
-            # (78.6 TFLOP/s); the kernel issues vector fp64 (DPP fmac), no MFMA.
-            "roofline": {"bound": "mfma", "achieved": flops / (step_ms_ev * 1e-3) / 1e12,
+                       "mean_active_set_iters": float(iters.mean()), "max_active_set_iters": int(iters.max()),
+                       "failed": n_fail, "max_stance_hint": (0 if args.no_hint else max_stance),
+                       "result_gather": ("rccl all_gather_into_tensor of grf per step" if gathered is not None else "none")},
+            # The path is compute-shaped, not HBM-shaped: the binding roof is the fp64
+            # VALU rate.  The kernel issues vector fp64 (DPP fmac), no MFMA; on MI355X the dense fp64
+            # MFMA peak is the same 78.6 TFLOP/s.
+            "roofline": {"bound": "fp64_valu", "achieved": flops / t_s / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (step_ms_ev * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "frac": flops / t_s / 1e12 / FP64_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "kernel": "qmpc_solve_kernel<1, false>", "kernel_ms_hip_events": step_ms_ev,
+                         "kernel": kname, "kernel_ms_hip_events": step_ms_ev,
                          "alg_flops_per_qp": flops / per_gpu,
-                         "note": "algorithmic fp64 flops F_alg(h, n_r, K) of SURVEY.md 8d over the HIP-event kernel "
-                                 "time, against the dense fp64 peak (MFMA == vector rate on MI355X); traffic = "
-                                 "HBM bytes per launch from PMC (profiles/pmc_latest.json)"},
+                         "executed_flops_per_qp": (executed / per_gpu if executed else None),
+                         "executed_tflops": (executed / t_s / 1e12 if executed else None),
+                         "executed_frac": (executed / t_s / 1e12 / FP64_PEAK_TFLOPS if executed else None),
+                         "note": "achieved/frac: algorithmic (reference-equivalent) fp64 flops F_alg(h, n_r, K) of "
+                                 "SURVEY.md 8d over the HIP-event kernel time; the closed-form assembly does not "
+                                 "execute F_cond, so executed_* (64 lanes x (2 FMA + MUL + ADD) fp64 wave-instructions, "
+                                 "PMC) is the honest utilisation figure. " + pmc_note},
             "roofline_hbm": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                              "alg_bytes_per_qp": alg_bytes_per_qp(h),
-                             "note": "728 B in + 48 B out per robot: tiny by construction"},
+                             "note": "728 B in + 48 B out per robot at h=10: tiny by construction"},
         }
+        if per_rank is not None:
+            res["per_rank"] = {"elapsed_s": per_rank,
+                               "qp_per_s": [per_gpu * args.steps / t for t in per_rank],
+                               "gathered_rows_match_local": gather_ok}
         if pipelined is not None:
             res["pipelined"] = pipelined
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(b)
+            res["cpu_baseline"] = cpu_baseline(b, spec, all_cores=not args.no_cpu_all_cores)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

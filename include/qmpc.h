@@ -152,6 +152,16 @@ int qmpc_solve(qmpc_handle h, int batch, const qmpc_inputs* in,
 int qmpc_solve_host(qmpc_handle h, int batch, const qmpc_inputs* in,
                     const qmpc_outputs* out);
 
+/* One host thread, several devices (SURVEY.md 8e / build plan step 4): `batch` robots given by
+ * HOST pointers are split into contiguous shards of ceil(batch / n_handles) robots, shard k is
+ * enqueued on handles[k] (its own device, its own stream: gather into that handle's pinned block,
+ * H2D, solve, D2H), and only after every device has been given its work are the results collected
+ * into the caller's arrays -- the devices run concurrently and no data-path collective is involved
+ * (robots are independent).  Every handle must have been set up with the same problem; several
+ * handles may share a device.  Returns the first error. */
+int qmpc_solve_sharded(const qmpc_handle* handles, int n_handles, int batch,
+                       const qmpc_inputs* in, const qmpc_outputs* out);
+
 /* Test hook: when non-NULL, the next qmpc_solve calls also store the
  * assembled reduced QP of every robot (before the solve) into DEVICE
  * buffers H[B][ld*ld], g[B][ld] (doubles, row-major, ld = qmpc_debug_ld();

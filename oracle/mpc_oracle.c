@@ -131,7 +131,7 @@ static void matmul_f(const float* A, const float* B, float* C, int r, int k,
 void oracle_c2d(const float* A, const float* B, float dt, float* Adt,
                 float* Bdt) {
   enum { N = 25 };
-  static float M[N * N], M2[N * N], M3[N * N], E[N * N];
+  float M[N * N], M2[N * N], M3[N * N], E[N * N]; /* (automatic: the restatement is re-entrant) */
   memset(M, 0, sizeof(M));
   for (int i = 0; i < 13; i++) {
     for (int j = 0; j < 13; j++) M[i * N + j] = dt * A[i * 13 + j];

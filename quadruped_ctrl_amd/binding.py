@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 5              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 6              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_NONFINITE = 32
 ST_ERROR_MASK = 15 | 32
@@ -22,7 +22,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
-           "qmpc_set_debug_aux"]
+           "qmpc_set_debug_aux", "qmpc_solve_sharded"]
 
 # qmpc_command fields (include/qmpc.h), in declaration order
 CMD_F32 = ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot",
@@ -81,6 +81,8 @@ def load_library():
         lib.qmpc_set_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
+        lib.qmpc_solve_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Inputs),
+                                           C.POINTER(Outputs)]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_min_stance.argtypes = [C.c_void_p, C.c_int]
@@ -286,6 +288,37 @@ class BatchedConvexMPC:
                       st.ctypes.data, it.ctypes.data)
         self._check(self.lib.qmpc_solve_host(self.h, B, C.byref(inp), C.byref(out)),
                     "qmpc_solve_host")
+        res = {"grf": grf, "status": st, "iters": it}
+        if full:
+            res["soln"] = soln
+        return res
+
+    @staticmethod
+    def solve_sharded(solvers, b, full=False):
+        """qmpc_solve_sharded: ONE host thread drives several handles (one per device in
+        production; several may share a device): contiguous shards of the host batch `b`, all
+        devices busy at once, results collected into one set of host arrays."""
+        first = solvers[0]
+        B, h = int(b["batch"]), first.horizon
+        keep = {k: np.ascontiguousarray(b[k], np.float32) for k in
+                ("p", "v", "q", "w", "r", "yaw", "traj", "weights", "alpha", "x_drag")}
+        keep["gait"] = np.ascontiguousarray(b["gait"], np.uint8)
+        inp = Inputs()
+        for k, a in keep.items():
+            setattr(inp, k, a.ctypes.data)
+        inp.weights_stride = 12 if keep["weights"].size == 12 * B else 0
+        inp.alpha_stride = 1 if keep["alpha"].size == B else 0
+        inp.x_drag_stride = 1 if keep["x_drag"].size == B else 0
+        grf = np.zeros((B, 12), np.float32)
+        st = np.zeros(B, np.int32)
+        it = np.zeros(B, np.int32)
+        soln = np.zeros((B, 12 * h)) if full else None
+        out = Outputs(grf.ctypes.data, soln.ctypes.data if full else None, st.ctypes.data, it.ctypes.data)
+        hs = (C.c_void_p * len(solvers))(*[m.h for m in solvers])
+        rc = first.lib.qmpc_solve_sharded(hs, len(solvers), B, C.byref(inp), C.byref(out))
+        if rc != QMPC_OK:
+            raise QmpcError(f"qmpc_solve_sharded failed rc={rc}: " +
+                            "; ".join(m.lib.qmpc_last_error(m.h).decode() for m in solvers))
         res = {"grf": grf, "status": st, "iters": it}
         if full:
             res["soln"] = soln

@@ -99,7 +99,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 5; }
+int qmpc_abi_version(void) { return 6; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -389,7 +389,21 @@ int qmpc_forces_to_body(qmpc_handle c, int batch, const float* r_body, const flo
   return QMPC_OK;
 }
 
-int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out) {
+}  // extern "C"
+
+namespace {
+
+// host-pointer solve in two halves, so that one host thread can keep several devices busy:
+// enqueue (gather into the pinned block, copies / launch on the handle's own stream) and finish
+// (wait for the event, scatter the results into the caller's arrays)
+struct HostJob {
+  size_t B = 0, h = 0;
+  size_t o_grf = 0, o_soln = 0, o_st = 0, o_it = 0;
+  qmpc_outputs out{};
+  bool active = false;
+};
+
+int host_enqueue(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_outputs* out, HostJob& job) {
   if (!c || !in || !out) return QMPC_ERR_ARG;
   if (!c->is_setup) return QMPC_ERR_STATE;
   if (batch <= 0 || batch > c->max_batch) return QMPC_ERR_ARG;
@@ -472,18 +486,83 @@ int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_
   if (rc != QMPC_OK) return rc;
   if (!in_place) HIP_TRY(c, hipMemcpyAsync(hb + in_bytes, base + in_bytes, out_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipEventRecord(c->host_ev, s));
-  // latency path: poll the event for a short while before handing the thread to the OS
-  {
-    hipError_t q = hipErrorNotReady;
-    for (int spin = 0; spin < 20000 && q == hipErrorNotReady; ++spin) q = hipEventQuery(c->host_ev);
-    if (q == hipErrorNotReady) q = hipEventSynchronize(c->host_ev);
-    if (q != hipSuccess) return fail(c, q, "qmpc_solve_host wait");
-  }
-  std::memcpy(out->grf, hb + o_grf, 4 * 12 * B);
-  if (out->soln) std::memcpy(out->soln, hb + o_soln, 8 * 12 * h * B);
-  std::memcpy(out->status, hb + o_st, 4 * B);
-  if (out->iters) std::memcpy(out->iters, hb + o_it, 4 * B);
+  job.B = B; job.h = h;
+  job.o_grf = o_grf; job.o_soln = o_soln; job.o_st = o_st; job.o_it = o_it;
+  job.out = *out;
+  job.active = true;
   return QMPC_OK;
+}
+
+int host_finish(qmpc_ctx* c, HostJob& job) {
+  if (!job.active) return QMPC_OK;
+  job.active = false;
+  DeviceGuard g(c->device);
+  // latency path: poll the event for a short while before handing the thread to the OS
+  hipError_t q = hipErrorNotReady;
+  for (int spin = 0; spin < 20000 && q == hipErrorNotReady; ++spin) q = hipEventQuery(c->host_ev);
+  if (q == hipErrorNotReady) q = hipEventSynchronize(c->host_ev);
+  if (q != hipSuccess) return fail(c, q, "qmpc_solve_host wait");
+  const char* hb = (const char*)c->h_pin;
+  const size_t B = job.B, h = job.h;
+  std::memcpy(job.out.grf, hb + job.o_grf, 4 * 12 * B);
+  if (job.out.soln) std::memcpy(job.out.soln, hb + job.o_soln, 8 * 12 * h * B);
+  std::memcpy(job.out.status, hb + job.o_st, 4 * B);
+  if (job.out.iters) std::memcpy(job.out.iters, hb + job.o_it, 4 * B);
+  return QMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out) {
+  HostJob job;
+  const int rc = host_enqueue(c, batch, in, out, job);
+  if (rc != QMPC_OK) return rc;
+  return host_finish(c, job);
+}
+
+int qmpc_solve_sharded(const qmpc_handle* handles, int n_handles, int batch, const qmpc_inputs* in,
+                       const qmpc_outputs* out) {
+  if (!handles || n_handles <= 0 || n_handles > 64 || !in || !out || batch < 0) return QMPC_ERR_ARG;
+  for (int k = 0; k < n_handles; ++k)
+    if (!handles[k]) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  if (!in->p || !in->v || !in->q || !in->w || !in->r || !in->yaw || !in->traj || !in->gait || !in->weights ||
+      !in->alpha || !in->x_drag || !out->grf || !out->status)
+    return QMPC_ERR_ARG;
+  const int h = handles[0]->horizon;
+  for (int k = 1; k < n_handles; ++k)
+    if (handles[k]->horizon != h) return QMPC_ERR_STATE;  // every device must be set up for the same problem
+  const int per = (batch + n_handles - 1) / n_handles;  // contiguous shards
+  HostJob jobs[64];
+  int rc_all = QMPC_OK;
+  // enqueue on every device first (each call returns as soon as its copies / launches are queued) ...
+  for (int k = 0; k < n_handles; ++k) {
+    const int lo = k * per, hi = (lo + per < batch) ? lo + per : batch;
+    if (lo >= hi) break;
+    const size_t o = (size_t)lo;
+    qmpc_inputs si = *in;
+    si.p = in->p + 3 * o; si.v = in->v + 3 * o; si.q = in->q + 4 * o; si.w = in->w + 3 * o;
+    si.r = in->r + 12 * o; si.yaw = in->yaw + o; si.traj = in->traj + (size_t)12 * h * o;
+    si.gait = in->gait + (size_t)4 * h * o;
+    si.weights = in->weights + (size_t)in->weights_stride * o;
+    si.alpha = in->alpha + (size_t)in->alpha_stride * o;
+    si.x_drag = in->x_drag + (size_t)in->x_drag_stride * o;
+    qmpc_outputs so;
+    so.grf = out->grf + 12 * o;
+    so.soln = out->soln ? out->soln + (size_t)12 * h * o : nullptr;
+    so.status = out->status + o;
+    so.iters = out->iters ? out->iters + o : nullptr;
+    const int rc = host_enqueue(handles[k], hi - lo, &si, &so, jobs[k]);
+    if (rc != QMPC_OK && rc_all == QMPC_OK) rc_all = rc;
+  }
+  // ... then collect: the devices run concurrently, one host thread drives them all
+  for (int k = 0; k < n_handles; ++k) {
+    const int rc = host_finish(handles[k], jobs[k]);
+    if (rc != QMPC_OK && rc_all == QMPC_OK) rc_all = rc;
+  }
+  return rc_all;
 }
 
 }  // extern "C"

@@ -105,6 +105,31 @@ __device__ __forceinline__ T pick(const T (&arr)[KW], int q) {
   for (int k = 1; k < KW; ++k) v = (q == k) ? arr[k] : v;
   return v;
 }
+// element idx (wave-uniform) of a vector stored 64 entries per register: arr[idx >> 6] at lane
+// idx & 63.  One readlane per register and a scalar select -- a select over the REGISTERS would be
+// turned into a dynamically indexed private array (scratch) by the compiler
+template <int KW>
+__device__ __forceinline__ double lane_elem(const double (&arr)[KW], int idx) {
+  const int q = idx >> 6, l = idx & 63;
+  double out = readlane_f64(arr[0], l);
+#pragma unroll
+  for (int k = 1; k < KW; ++k) {
+    const double t = readlane_f64(arr[k], l);
+    out = (q == k) ? t : out;
+  }
+  return out;
+}
+template <int KW>
+__device__ __forceinline__ int lane_elem(const int (&arr)[KW], int idx) {
+  const int q = idx >> 6, l = idx & 63;
+  int out = __builtin_amdgcn_readlane(arr[0], l);
+#pragma unroll
+  for (int k = 1; k < KW; ++k) {
+    const int t = __builtin_amdgcn_readlane(arr[k], l);
+    out = (q == k) ? t : out;
+  }
+  return out;
+}
 // 1/d to full double precision: v_rcp_f64 seed + two Newton steps
 __device__ __forceinline__ double fast_rcp(double d) {
   double x = __builtin_amdgcn_rcp(d);
@@ -305,7 +330,7 @@ struct Smem {
 // Schur form that never overflows.  Both are run by wave 0 alone.  Returns true
 // when the robot must be re-run with the other engine.
 template <int RB, bool V5, bool CMD>
-__device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
+__device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
   const QmpcParams& P = S.par;  // parked copy: everything after stage 0
@@ -687,13 +712,33 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     // their foot-step ids in one batch, then the table / E loads in groups of 4
     constexpr int NSL = CW / 3 + 2;
     const int cslot0 = (c * CW) / 3, cax0 = (c * CW) % 3;
-    int kjs[NSL];
+    // (the largest class packs the ids four to a register: it has no VGPRs to spare)
+    constexpr bool PACK = (RB == 3);
+    int kjs[PACK ? (NSL + 3) / 4 : NSL];
+    if constexpr (PACK) {
 #pragma unroll
-    for (int q = 0; q < NSL; ++q) {  // unconditional (clamped) loads: all in flight together
-      const int sl = cslot0 + q;
-      const int kv = (int)S.sidx[sl < 63 ? sl : 63];
-      kjs[q] = (sl < nst) ? kv : 0;
+      for (int q4 = 0; q4 < (NSL + 3) / 4; ++q4) {
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int sl = cslot0 + 4 * q4 + b;
+          const unsigned kv = S.sidx[sl < 63 ? sl : 63];
+          w |= ((sl < nst) ? kv : 0u) << (8 * b);
+        }
+        kjs[q4] = (int)w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NSL; ++q) {  // unconditional (clamped) loads: all in flight together
+        const int sl = cslot0 + q;
+        const int kv = (int)S.sidx[sl < 63 ? sl : 63];
+        kjs[q] = (sl < nst) ? kv : 0;
+      }
     }
+    auto kj_at = [&](int q) __attribute__((always_inline)) {  // q is a compile-time constant at every call site
+      if constexpr (PACK) return (int)(((unsigned)kjs[q >> 2] >> (8 * (q & 3))) & 0xffu);
+      else return kjs[q];
+    };
     // branch-free element loop (indices are always in range: out-of-range rows /
     // columns read slot 0 and are overwritten by the padding select), so the LDS
     // loads of a group of elements are in flight together.  The (slot, axis) walk
@@ -704,11 +749,11 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
       for (int jj = 0; jj < CW; ++jj) {
         constexpr int dummy = 0;
         (void)dummy;
-        const int kj = kjs[(CAX0 + jj) / 3], cax = (CAX0 + jj) % 3;
+        const int kj = kj_at((CAX0 + jj) / 3), cax = (CAX0 + jj) % 3;
         const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + cax;
         // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
         a[jj] = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
-        if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+        if ((jj & (RB == 3 ? 1 : 3)) == (RB == 3 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
       }
       if (drag) {  // uniform
         // E_01 / E_12 couple (z of foot-step i, x of foot-step j); E_10 / E_21 the
@@ -716,13 +761,14 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         const double w11 = Aa.W[11] * dm2, w5 = Aa.W[5] * dm2, w5x = Aa.W[5] * (x_drag * dm2);
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) {
-          const int kj = kjs[(CAX0 + jj) / 3], cax = (CAX0 + jj) % 3;
+          const int kj = kj_at((CAX0 + jj) / 3), cax = (CAX0 + jj) % 3;
           const int sj = kj >> 2, cidx = si * h + sj, tidx = sj * h + si;
           double add = 0.0;
           if (ai == 2 && cax == 0) add = Aa.ct1[cidx] * w11 + Aa.ct5[cidx] * w5;
           if (ai == 0 && cax == 2) add = Aa.ct1[tidx] * w11 + Aa.ct5[tidx] * w5;
           if (ai == 0 && cax == 0) add = Aa.ct8[cidx] * w5x;
           a[jj] += add;
+          if (RB == 3 || (jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (as above: the largest class has no VGPRs to spare)
         }
       }
     };
@@ -1082,7 +1128,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
         return out;
       };
       auto bcast = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
-        return readlane_f64(pick<RE>(v, (j >> 6) < RE ? (j >> 6) : 0), j & 63);
+        return lane_elem<RE>(v, j);
       };
       // element (row = lane + 64 q, column j) of H^-1 for a wave-uniform j
       auto Hcol = [&](int q, int j) __attribute__((always_inline)) {
@@ -1377,7 +1423,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
     };
     // the same for a wave-uniform j
     auto bcast = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
-      return readlane_f64(pick<RE>(v, (j >> 6) < RE ? (j >> 6) : 0), j & 63);
+      return lane_elem<RE>(v, j);
     };
     // row w of M = H^-1 C_W lives at the back of the pool while it does not collide with S_W^-1
     // The packed inverse only occupies n(n+1)/2 doubles of Hp: the working-set storage
@@ -1483,8 +1529,8 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int v = v0 + u;
-            double dv = readlane_f64(pick<KW>(dw, (v >> 6) < KW ? (v >> 6) : 0), v & 63);
-            const int ev = __builtin_amdgcn_readlane(pick<KW>(wcid, (v >> 6) < KW ? (v >> 6) : 0), v & 63);
+            double dv = lane_elem<KW>(dw, v);
+            const int ev = lane_elem<KW>(wcid, v);
             if (v >= khw || ev < 0) dv = 0.0;
 #pragma unroll
             for (int q = 0; q < KW; ++q) rw[q] = __builtin_fma(sv[q][u], dv, rw[q]);
@@ -1508,15 +1554,15 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int w = w0 + u;
-              const double rv = (w < wfast) ? readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63) : 0.0;
+              const double rv = (w < wfast) ? lane_elem<KW>(rw, w) : 0.0;
 #pragma unroll
               for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(-rv, mv[u][q], z[q]);
             }
           }
           for (int w = wfast; w < khw; ++w) {  // rows that did not fit the pool: recompute from Hp
-            const int e = __builtin_amdgcn_readlane(pick<KW>(wcid, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
+            const int e = lane_elem<KW>(wcid, w);
             if (e < 0) continue;  // uniform
-            const double rv = readlane_f64(pick<KW>(rw, (w >> 6) < KW ? (w >> 6) : 0), w & 63);
+            const double rv = lane_elem<KW>(rw, w);
             int j1, j2;
             double a1, a2;
             con_coefs(e, mi, j1, j2, a1, a2);
@@ -1613,7 +1659,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int hi = h0 + u;
-              const double rhi = readlane_f64(pick<KW>(rw, (hi >> 6) < KW ? (hi >> 6) : 0), hi & 63);
+              const double rhi = lane_elem<KW>(rw, hi);
 #pragma unroll
               for (int q = 0; q < KW; ++q) {
                 const int lo = lane + 64 * q;
@@ -1671,7 +1717,7 @@ __device__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcP
           if (w < khw) swp[sym_idx(w, l)] = 0.0;
         }
         // the dropped constraint leaves its slot: clear lane-w and lane-sl state
-        const int de = __builtin_amdgcn_readlane(pick<KW>(wcid, (l >> 6) < KW ? (l >> 6) : 0), l & 63);
+        const int de = lane_elem<KW>(wcid, l);
 #pragma unroll
         for (int q = 0; q < KW; ++q)
           if (lane + 64 * q == l) {

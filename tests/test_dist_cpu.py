@@ -1,5 +1,11 @@
-"""CPU suite: the N>1 path (independent robot shards, no data-path collective,
-max-over-ranks timing) on world_size=2 with the gloo backend."""
+"""CPU suite: the N>1 PLUMBING (independent robot shards, the result gather, max-over-ranks
+timing) on world_size=2 with the gloo backend.
+
+Sharding / collective arithmetic ONLY: there is no GPU here, so the per-rank "solve" is the
+oracle standing in for the HIP solver (no product compute is exercised).  The product-side
+N>1 path -- per-rank handles, RCCL all_gather_into_tensor of grf, per-rank timing -- runs in
+the -m gpu suite (test_bench_two_ranks_dry_run, test_bench_two_ranks_gather) and on hardware
+in the driver's SCALE run."""
 import os
 import sys
 
@@ -29,8 +35,13 @@ def _worker(rank, world, port, outdir):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([mine["batch"]], dtype=torch.int64))
+    # result collection as bench.py --gather does it: ONE all_gather_into_tensor of
+    # the 12 first-step forces per robot; every rank ends up with every robot's forces
+    grf = torch.from_numpy(np.ascontiguousarray(q[:, :12], np.float32))
+    gathered = torch.empty((world * grf.shape[0], 12), dtype=torch.float32)
+    dist.all_gather_into_tensor(gathered, grf)
     np.savez(os.path.join(outdir, f"r{rank}.npz"), q=q, tmax=t.numpy(),
-             sizes=np.array([int(s) for s in sizes]))
+             sizes=np.array([int(s) for s in sizes]), gathered=gathered.numpy())
     dist.destroy_process_group()
 
 
@@ -48,3 +59,5 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     assert np.array_equal(np.concatenate([p["q"] for p in parts]), qref)
     assert all(p["tmax"][0] == 2.0 for p in parts)
     assert parts[0]["sizes"].tolist() == [5, 5]
+    for p in parts:       # every rank holds the single-process result after the gather
+        assert np.array_equal(p["gathered"], qref[:, :12].astype(np.float32))

@@ -455,6 +455,33 @@ def test_one_handle_two_streams_is_ordered(mpc_factory):
     assert np.array_equal(again["soln"], want["soln"])
 
 
+def test_sharded_host_driver(mpc_factory):
+    """qmpc_solve_sharded (SURVEY 8e / build plan step 4): one host thread, several handles, contiguous
+    shards, no collective.  Here every handle sits on this box's one GPU; on an 8-GPU node each gets its
+    own device.  Results equal the single-handle host path bit for bit, for even and ragged splits, with
+    per-robot and with shared (stride-0) parameters; errors are reported, not swallowed."""
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC, QmpcError
+    b = W.make_config(4, batch=1001)                       # several size classes
+    whole = mpc_factory(b).solve_host(b, full=True)
+    for n in (1, 2, 3, 8):
+        ms = [mpc_factory(b, max_batch=-(-1001 // n)) for _ in range(n)]
+        got = BatchedConvexMPC.solve_sharded(ms, b, full=True)
+        for k in ("grf", "soln", "status", "iters"):
+            assert np.array_equal(got[k], whole[k]), (n, k)
+    shared = dict(b)
+    shared["weights"] = b["weights"][0].copy()
+    shared["alpha"] = b["alpha"][:1].copy()
+    shared["x_drag"] = b["x_drag"][:1].copy()
+    ms = [mpc_factory(b, max_batch=501) for _ in range(2)]
+    got = BatchedConvexMPC.solve_sharded(ms, shared, full=True)
+    assert np.array_equal(got["soln"], whole["soln"])
+    few = W.shard(b, 0, 200)                               # fewer robots than handles would get: idle handles
+    got = BatchedConvexMPC.solve_sharded([mpc_factory(b, max_batch=8) for _ in range(4)], few, full=True)
+    assert np.array_equal(got["soln"], whole["soln"][:few["batch"]])
+    with pytest.raises(QmpcError):                         # a shard larger than its handle's max_batch
+        BatchedConvexMPC.solve_sharded([mpc_factory(b, max_batch=100) for _ in range(2)], b)
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
@@ -758,6 +785,25 @@ def test_bench_two_ranks_dry_run():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["failed"] == 0
     assert d["value"] > 1e6 and "cpu_baseline" not in d
+
+
+def test_bench_two_ranks_gather():
+    """bench.py --gpus 2 --gather: one all_gather_into_tensor of grf per step inside the timed region;
+    every rank's slice of the gathered tensor equals its local result, per-rank rates are reported."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, QMPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "3", "--settle", "0", "--gather", "--config", "2",
+                          "--batch", "512"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["failed"] == 0
+    assert d["per_rank"]["gathered_rows_match_local"] is True and len(d["per_rank"]["qp_per_s"]) == 2
+    assert "all_gather" in d["config"]["result_gather"]
 
 
 def test_empty_batch_and_argument_errors(mpc_factory):

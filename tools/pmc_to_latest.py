@@ -1,0 +1,35 @@
+"""Fold a tools/pmc.sh run into profiles/pmc_latest.json (what bench.py's roofline.traffic and
+roofline.executed_* read), stamped with the hash of the kernel source it was collected on.
+
+    python tools/pmc_to_latest.py gpurun_out/<dir> <workload-key> <batch> <profile-name>
+e.g. python tools/pmc_to_latest.py gpurun_out/r02_pmc_cfg1 config1 1024 profiles/r02_a_pmc_summary.json
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
+src, key, batch, prof = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+summ = json.load(open(os.path.join(src, "pmc_summary.json")))
+# the dominant solve kernel of the run: the one with the most busy cycles
+name, d = max(((k, v) for k, v in summ.items() if "qmpc_solve_kernel" in k), key=lambda kv: kv[1].get("SQ_WAVE_CYCLES", 0))
+fetch, write = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)     # KiB per dispatch
+flops = 64.0 * (2.0 * d.get("SQ_INSTS_VALU_FMA_F64", 0.0) + d.get("SQ_INSTS_VALU_MUL_F64", 0.0) + d.get("SQ_INSTS_VALU_ADD_F64", 0.0))
+path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+latest = json.load(open(path)) if os.path.exists(path) else {}
+latest[key] = {
+    "kernel": name, "batch": batch, "profile": prof, "kernel_source_sha": kernel_source_hash(),
+    # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB... on gfx950 the read side is
+    # under-reported by 2x for 64-byte requests: doubled here (upper bound for this narrow-access kernel)
+    "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+    "fetch_size_kib": fetch, "write_size_kib": write,
+    "fp64_flops_per_launch": flops,
+    "fp64_wave_insts": {k: d.get(k) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU")},
+    "wave_cycle_shares": {k: (d.get(k, 0.0) / d["SQ_WAVE_CYCLES"] if d.get("SQ_WAVE_CYCLES") else None)
+                          for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")},
+}
+json.dump(latest, open(path, "w"), indent=1)
+print(json.dumps(latest[key], indent=1))

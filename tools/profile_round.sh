@@ -1,0 +1,27 @@
+#!/bin/bash
+# One round's measurement set, run on the GPU box:  gpurun -- 'bash tools/profile_round.sh r02_a'
+# For configs[1] and the standing / horizon-16 workloads (size classes 1, 2, 3, 4):
+#   bench line (+ CPU baseline), rocprofv3 --kernel-trace --stats summary of the same command, PMC passes.
+# Everything lands under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=$1
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, bench args...
+  local name=$1; shift
+  python $R/bench.py --steps 300 "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$name -o s --output-format csv -- \
+      python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-pipelined "$@" > $OUT/stats_$name.log 2>&1
+  find $OUT/stats_$name -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$name.csv \;
+  bash $R/tools/pmc.sh $TAG/pmc_$name --no-pipelined "$@" > $OUT/pmc_$name.log 2>&1
+  cp $OUT/pmc_$name/pmc_summary.json $OUT/pmc_summary_$name.json 2>/dev/null
+  rm -rf $OUT/stats_$name $OUT/pmc_$name/p*
+}
+run cfg1
+run standing_h10 --workload standing --horizon 10
+run standing_h14 --workload standing --horizon 14
+run standing_h16 --workload standing --horizon 16
+run trot_h16 --config 3
+ls -la $OUT
