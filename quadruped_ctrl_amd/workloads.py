@@ -115,11 +115,19 @@ def make_config(idx, batch=None):
     raise ValueError(idx)
 
 
-def make_standing(batch, horizon=10, seed=99):
+def make_standing(batch, horizon=10, seed=99, calm=False):
     """All four feet in stance for every step (n_r = 12h): the reference's
-    'Standing' gait (ConvexMPCLocomotion.cpp:35) -- largest reduced QP."""
+    'Standing' gait (ConvexMPCLocomotion.cpp:35) -- largest reduced QP.
+    Default states are SURVEY 8d's (v_x ~ 0.5 m/s) against a zero-velocity reference, i.e. a
+    robot BRAKING to a stand: the backward friction limit binds on most foot-steps (30+ active
+    constraints, the solver's worst case).  calm=True: a robot that already stands
+    (|v| ~ 2 cm/s, small attitude / rate errors), which is what the gait is used for."""
     rng = np.random.default_rng(SEED0 + seed)
     d = _states(rng, batch, horizon)
+    if calm:
+        f32 = np.float32
+        d["v"] = rng.normal(0, 0.02, (batch, 3)).astype(f32)
+        d["w"] = rng.normal(0, 0.05, (batch, 3)).astype(f32)
     d["traj"].reshape(batch, horizon, 12)[:, :, 9] = 0
     d["traj"].reshape(batch, horizon, 12)[:, :, 3] = d["p"][:, 0:1]
     return _finish(d, batch, horizon, np.ones((batch, 4 * horizon), np.uint8))

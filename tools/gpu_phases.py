@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from quadruped_ctrl_amd import workloads as W
 from quadruped_ctrl_amd.binding import BatchedConvexMPC
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cfg = sys.argv[1] if len(sys.argv) > 1 else "1"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-b = W.make_config(cfg, batch=B)
+# "1".."4" = BASELINE configs; "s10" / "s14" / "s16" = standing at that horizon; "c10".. = calm standing
+b = (W.make_standing(B, int(cfg[1:]), calm=(cfg[0] == "c")) if cfg[0] in "sc" else W.make_config(int(cfg), batch=B))
 mpc = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
 mpc.setup(b["dt"], b["horizon"], b["mu"], b["f_max"])
 d = mpc.upload(b); o = mpc.alloc_outputs(B); inp, out = mpc.make_args(d, o)
