@@ -250,6 +250,57 @@ int qmpc_forces_to_body(qmpc_handle h, int batch, const float* r_body,
 int qmpc_solve_commands(qmpc_handle h, int batch, const qmpc_command* cmd,
                         const qmpc_outputs* out, float* f_ff, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Per-tick glue either side of the solve, batched.  One row per robot in every
+ * array, DEVICE pointers, float arithmetic written operation by operation after the reference
+ * (only the libm calls -- sin / cos / atan2 / sqrt -- may differ from the host's by an ulp).
+ * Leg order 0..3 = FR, FL, RR, RL with side signs -1, +1, -1, +1 (src/Dynamics/Quadruped.h:85-89);
+ * joint order abad, hip, knee; everything in the leg's hip frame like LegControllerData.
+ */
+
+/* Leg link lengths; defaults are the Mini Cheetah's (src/Dynamics/MiniCheetah.h:31-37):
+ * abad 0.062, hip 0.209, knee 0.195, knee Y offset 0.004. */
+int qmpc_set_leg_geometry(qmpc_handle h, double abad_link, double hip_link, double knee_link,
+                          double knee_link_y_offset);
+
+/* LegController::updateData (src/Controllers/LegController.cpp:89-110): for every leg the foot
+ * position p[B][12] and Jacobian J[B][4][9] (row-major 3x3) of computeLegJacobianAndPosition
+ * (:204-244) from the joint angles q[B][12] (q[3*leg + joint]), and, when v is non-NULL, the foot
+ * velocity v = J * qd (:108). */
+int qmpc_leg_kinematics(qmpc_handle h, int batch, const float* q, const float* qd, float* J,
+                        float* p, float* v, void* stream);
+
+/* What LegController::updateCommand (:116-160) reads. */
+typedef struct {
+  const float* tau_ff;   /* [B][12] commands[leg].tauFeedForward   (NULL = zeros) */
+  const float* force_ff; /* [B][12] commands[leg].forceFeedForward (NULL = zeros) -- the f_ff of the MPC */
+  const float* kp_cart;  /* [B][4][9] kpCartesian, row-major Mat3 per leg */
+  const float* kd_cart;  /* [B][4][9] kdCartesian */
+  const float* p_des;    /* [B][12] commands[leg].pDes */
+  const float* v_des;    /* [B][12] commands[leg].vDes */
+  const float* q;        /* [B][12] datas[leg].q  */
+  const float* qd;       /* [B][12] datas[leg].qd */
+  const float* J;        /* [B][4][9] datas[leg].J (qmpc_leg_kinematics) */
+  const float* p;        /* [B][12] datas[leg].p */
+  const float* v;        /* [B][12] datas[leg].v */
+  float kp_joint;        /* crtlParam(2) (GaitCtrller.cpp:15,128) */
+  float kd_joint;        /* crtlParam(3) */
+} qmpc_leg_command;
+
+/* LegController::updateCommand: footForce = forceFF + Kp (pDes - p) + Kd (vDes - v);
+ * legTorque = tauFF + J^T footForce; tau[B][12] (tau[3*leg + joint] == JointEff::eff,
+ * GaitCtrller.cpp:130-136) = kp_joint (0 - q) - kd_joint qd + legTorque.  q_des[B][12]
+ * (optional) = computeLegIK(pDes) (:255-285). */
+int qmpc_leg_torques(qmpc_handle h, int batch, const qmpc_leg_command* cmd, float* tau,
+                     float* q_des, void* stream);
+
+/* FootSwingTrajectory::computeSwingTrajectoryBezier (src/Controllers/FootSwingTrajectory.cpp:17-37)
+ * for n_feet independent swing feet: start p0[n][3], landing pf[n][3], apex height[n], swing phase[n]
+ * in [0, 1], swing_time[n] seconds -> position p, velocity v, acceleration a ([n][3] each). */
+int qmpc_swing_trajectory(qmpc_handle h, int n_feet, const float* p0, const float* pf,
+                          const float* height, const float* phase, const float* swing_time,
+                          float* p, float* v, float* a, void* stream);
+
 /* Last HIP error string for this handle ("" if none). */
 const char* qmpc_last_error(qmpc_handle h);
 

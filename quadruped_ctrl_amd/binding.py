@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 6              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 7              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_NONFINITE = 32
 ST_ERROR_MASK = 15 | 32
@@ -22,7 +22,11 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_solve_host", "qmpc_set_debug", "qmpc_debug_ld",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
-           "qmpc_set_debug_aux", "qmpc_solve_sharded"]
+           "qmpc_set_debug_aux", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
+           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory"]
+
+# qmpc_leg_command fields (include/qmpc.h), in declaration order
+LEG_F32 = ("tau_ff", "force_ff", "kp_cart", "kd_cart", "p_des", "v_des", "q", "qd", "J", "p", "v")
 
 # qmpc_command fields (include/qmpc.h), in declaration order
 CMD_F32 = ("position", "v_world", "omega_world", "orientation", "rpy", "r_body", "p_foot",
@@ -54,6 +58,10 @@ class Record(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in REC_FIELDS]
 
 
+class LegCommand(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in LEG_F32] + [("kp_joint", C.c_float), ("kd_joint", C.c_float)]
+
+
 _lib = None
 
 
@@ -81,6 +89,10 @@ def load_library():
         lib.qmpc_set_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
+        lib.qmpc_set_leg_geometry.argtypes = [C.c_void_p] + [C.c_double] * 4
+        lib.qmpc_leg_kinematics.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        lib.qmpc_leg_torques.argtypes = [C.c_void_p, C.c_int, C.POINTER(LegCommand), C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.qmpc_swing_trajectory.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9
         lib.qmpc_solve_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Inputs),
                                            C.POINTER(Outputs)]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
@@ -292,6 +304,50 @@ class BatchedConvexMPC:
         if full:
             res["soln"] = soln
         return res
+
+    # ---- per-tick glue either side of the solve ---------------------------
+    def _dev32(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+
+    def _stream_ptr(self, stream):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    def leg_kinematics(self, q, qd, stream=None):
+        """LegController::updateData on device tensors q, qd [B,12] -> J [B,4,9], p [B,12], v [B,12]."""
+        t = self.torch
+        B = q.shape[0]
+        J = t.empty((B, 4, 9), dtype=t.float32, device=self.device)
+        p = t.empty((B, 12), dtype=t.float32, device=self.device)
+        v = t.empty((B, 12), dtype=t.float32, device=self.device)
+        self._check(self.lib.qmpc_leg_kinematics(self.h, B, q.data_ptr(), qd.data_ptr(), J.data_ptr(), p.data_ptr(),
+                                                 v.data_ptr(), self._stream_ptr(stream)), "qmpc_leg_kinematics")
+        return J, p, v
+
+    def leg_torques(self, c, stream=None):
+        """LegController::updateCommand: dict of device tensors (LEG_F32 keys; tau_ff / force_ff may be
+        None) + kp_joint, kd_joint -> tau [B,12], q_des [B,12]."""
+        t = self.torch
+        B = c["q"].shape[0]
+        lc = LegCommand()
+        for k in LEG_F32:
+            setattr(lc, k, None if c.get(k) is None else c[k].data_ptr())
+        lc.kp_joint, lc.kd_joint = float(c["kp_joint"]), float(c["kd_joint"])
+        tau = t.empty((B, 12), dtype=t.float32, device=self.device)
+        qdes = t.empty((B, 12), dtype=t.float32, device=self.device)
+        self._check(self.lib.qmpc_leg_torques(self.h, B, C.byref(lc), tau.data_ptr(), qdes.data_ptr(),
+                                              self._stream_ptr(stream)), "qmpc_leg_torques")
+        return tau, qdes
+
+    def swing_trajectory(self, p0, pf, height, phase, swing_time, stream=None):
+        """computeSwingTrajectoryBezier for n feet: device tensors [n,3], [n,3], [n], [n], [n] -> p, v, a."""
+        t = self.torch
+        n = p0.shape[0]
+        p, v, a = (t.empty((n, 3), dtype=t.float32, device=self.device) for _ in range(3))
+        self._check(self.lib.qmpc_swing_trajectory(self.h, n, p0.data_ptr(), pf.data_ptr(), height.data_ptr(),
+                                                   phase.data_ptr(), swing_time.data_ptr(), p.data_ptr(), v.data_ptr(),
+                                                   a.data_ptr(), self._stream_ptr(stream)), "qmpc_swing_trajectory")
+        return p, v, a
 
     @staticmethod
     def solve_sharded(solvers, b, full=False):

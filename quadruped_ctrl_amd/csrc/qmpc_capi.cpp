@@ -20,6 +20,13 @@ extern "C" hipError_t qmpc_prepare(void);
 extern "C" hipError_t qmpc_launch_pack(const qmpc_command* c, const qmpc_record* rec, int batch, int horizon, float dt_mpc,
                                        hipStream_t stream);
 extern "C" hipError_t qmpc_launch_f2b(const float* r_body, const float* grf, float* f_ff, int batch, hipStream_t stream);
+extern "C" hipError_t qmpc_launch_leg_kin(const float geom[4], const float* q, const float* qd, float* J, float* p,
+                                          float* v, int batch, hipStream_t stream);
+extern "C" hipError_t qmpc_launch_leg_cmd(const float geom[4], const qmpc_leg_command* c, float* tau, float* q_des,
+                                          int batch, hipStream_t stream);
+extern "C" hipError_t qmpc_launch_swing(const float* p0, const float* pf, const float* height, const float* phase,
+                                        const float* swing_time, float* p, float* v, float* a, int n_feet,
+                                        hipStream_t stream);
 
 struct qmpc_ctx {
   int device = 0;
@@ -32,6 +39,7 @@ struct qmpc_ctx {
   double gravity = -9.8f;                  // SolverMPC.cpp:318
   int max_iter = 1000;
   double tol = 1e-9;
+  float leg_geom[4] = {0.062f, 0.209f, 0.195f, 0.004f};  // MiniCheetah.h:31-37 (abad, hip, knee, knee Y offset)
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
   int* d_lists = nullptr;      // [3][max_batch] robot ids handed to classes 4, 2 and 3
   int* d_counts = nullptr;     // [2 sets][4]: list lengths of classes 4, 2, 3 (+pad), ping-ponged between calls
@@ -99,7 +107,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 6; }
+int qmpc_abi_version(void) { return 7; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -514,6 +522,47 @@ int host_finish(qmpc_ctx* c, HostJob& job) {
 }  // namespace
 
 extern "C" {
+
+int qmpc_set_leg_geometry(qmpc_handle c, double abad, double hip, double knee, double knee_y) {
+  if (!c || !(abad >= 0) || !(hip > 0) || !(knee > 0)) return QMPC_ERR_ARG;
+  c->leg_geom[0] = (float)abad;
+  c->leg_geom[1] = (float)hip;
+  c->leg_geom[2] = (float)knee;
+  c->leg_geom[3] = (float)knee_y;
+  return QMPC_OK;
+}
+
+int qmpc_leg_kinematics(qmpc_handle c, int batch, const float* q, const float* qd, float* J, float* p, float* v,
+                        void* stream) {
+  if (!c || !q || !J || !p || (v && !qd)) return QMPC_ERR_ARG;
+  if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, qmpc_launch_leg_kin(c->leg_geom, q, qd, J, p, v, batch, (hipStream_t)stream));
+  return QMPC_OK;
+}
+
+int qmpc_leg_torques(qmpc_handle c, int batch, const qmpc_leg_command* cmd, float* tau, float* q_des, void* stream) {
+  if (!c || !cmd || !tau) return QMPC_ERR_ARG;
+  if (!cmd->kp_cart || !cmd->kd_cart || !cmd->p_des || !cmd->v_des || !cmd->q || !cmd->qd || !cmd->J || !cmd->p ||
+      !cmd->v)
+    return QMPC_ERR_ARG;
+  if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, qmpc_launch_leg_cmd(c->leg_geom, cmd, tau, q_des, batch, (hipStream_t)stream));
+  return QMPC_OK;
+}
+
+int qmpc_swing_trajectory(qmpc_handle c, int n_feet, const float* p0, const float* pf, const float* height,
+                          const float* phase, const float* swing_time, float* p, float* v, float* a, void* stream) {
+  if (!c || !p0 || !pf || !height || !phase || !swing_time || !p || !v || !a) return QMPC_ERR_ARG;
+  if (n_feet < 0 || n_feet > 4 * c->max_batch) return QMPC_ERR_ARG;
+  if (n_feet == 0) return QMPC_OK;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, qmpc_launch_swing(p0, pf, height, phase, swing_time, p, v, a, n_feet, (hipStream_t)stream));
+  return QMPC_OK;
+}
 
 int qmpc_solve_host(qmpc_handle c, int batch, const qmpc_inputs* in, const qmpc_outputs* out) {
   HostJob job;

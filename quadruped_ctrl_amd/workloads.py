@@ -211,3 +211,38 @@ def make_commands(batch, horizon=10, seed=7, stand_fraction=0.1, omni_mode=0, ca
         "body_height": 0.29, "omni_mode": int(omni_mode),
     }
     return cmd
+
+
+def make_leg_states(batch, seed=3):
+    """Synthetic joint states and leg commands for the per-tick glue (include/qmpc.h
+    qmpc_leg_kinematics / qmpc_leg_command; LegController.cpp:89-160): joint angles around the
+    Mini Cheetah's stance posture, joint rates, Cartesian gains of the reference's magnitude
+    (ConvexMPCLocomotion.cpp Kp ~ diag(700, 700, 150), Kd ~ diag(7, 7, 7)) with small off-diagonal
+    terms so that every matrix entry is exercised, foot targets a few centimetres from the foot."""
+    rng = np.random.default_rng(SEED0 + 1000 + seed)
+    f32 = np.float32
+    B = batch
+    q = np.tile(np.array([0.0, -0.8, 1.6]), (B, 4)) + rng.normal(0, [0.15, 0.3, 0.3] * 4, (B, 12))
+    qd = rng.normal(0, 2.0, (B, 12))
+    kp = np.tile(np.diag([700.0, 700.0, 150.0]).reshape(9), (B, 4, 1)) + rng.normal(0, 5.0, (B, 4, 9))
+    kd = np.tile(np.diag([7.0, 7.0, 7.0]).reshape(9), (B, 4, 1)) + rng.normal(0, 0.1, (B, 4, 9))
+    return {"batch": B, "q": q.astype(f32), "qd": qd.astype(f32),
+            "kp_cart": kp.astype(f32), "kd_cart": kd.astype(f32),
+            "dp_des": rng.normal(0, 0.03, (B, 12)).astype(f32), "v_des": rng.normal(0, 0.5, (B, 12)).astype(f32),
+            "tau_ff": rng.normal(0, 0.5, (B, 12)).astype(f32), "force_ff": rng.normal(0, 30.0, (B, 12)).astype(f32),
+            "kp_joint": 3.0, "kd_joint": 0.5}
+
+
+def make_swing_states(n, seed=4):
+    """n swing feet: start / landing points ~0.2 m apart, apex 6-10 cm, phase in [0, 1] (including
+    exactly 0, 0.5 and 1), swing times of 5-9 MPC steps (FootSwingTrajectory.cpp:17-37)."""
+    rng = np.random.default_rng(SEED0 + 2000 + seed)
+    f32 = np.float32
+    p0 = rng.normal(0, 0.3, (n, 3))
+    p0[:, 2] = rng.normal(0, 0.02, n)
+    pf = p0 + rng.normal(0, 0.15, (n, 3))
+    pf[:, 2] = rng.normal(0, 0.03, n)
+    phase = rng.random(n)
+    phase[:3] = [0.0, 0.5, 1.0][:min(3, n)]
+    return {"p0": p0.astype(f32), "pf": pf.astype(f32), "height": rng.uniform(0.06, 0.1, n).astype(f32),
+            "phase": phase.astype(f32), "swing_time": (0.026 * rng.integers(5, 10, n)).astype(f32)}

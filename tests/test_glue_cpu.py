@@ -1,0 +1,85 @@
+"""CPU suite for the per-tick glue restatement (oracle/glue_oracle.c): the float
+restatement is checked against the mathematics it restates (no GPU, no reference build:
+LegController / FootSwingTrajectory need Eigen, so their parity is unpinned like the assembly)."""
+import numpy as np
+
+from oracle import glue as G
+from quadruped_ctrl_amd import workloads as W
+
+
+def fk64(q, leg, g=G.GEOM.astype(np.float64)):
+    """Independent fp64 forward kinematics from the leg geometry: abad rotation about x, hip and knee
+    about y (Mini Cheetah convention of computeLegJacobianAndPosition)."""
+    l1, l2, l3, l4 = g
+    side = -1.0 if leg % 2 == 0 else 1.0
+    s1, c1 = np.sin(q[0]), np.cos(q[0])
+    s2, c2 = np.sin(q[1]), np.cos(q[1])
+    s23, c23 = np.sin(q[1] + q[2]), np.cos(q[1] + q[2])
+    x = l3 * s23 + l2 * s2
+    zz = -(l3 * c23 + l2 * c2)          # leg-plane "down" before the abad rotation
+    yy = (l1 + l4) * side
+    return np.array([x, yy * c1 - zz * s1, yy * s1 + zz * c1])
+
+
+def test_fk_position_and_jacobian():
+    s = W.make_leg_states(64)
+    J, p, v = G.leg_update(s["q"], s["qd"])
+    for b in range(0, 64, 7):
+        for leg in range(4):
+            q = s["q"][b, 3 * leg:3 * leg + 3].astype(np.float64)
+            ref = fk64(q, leg)
+            assert np.abs(p[b, 3 * leg:3 * leg + 3] - ref).max() < 2e-6
+            # Jacobian = d p / d q (central differences of the fp64 model)
+            Jn = np.zeros((3, 3))
+            for k in range(3):
+                e = np.zeros(3); e[k] = 1e-6
+                Jn[:, k] = (fk64(q + e, leg) - fk64(q - e, leg)) / 2e-6
+            assert np.abs(J[b, leg].reshape(3, 3) - Jn).max() < 2e-5
+            assert np.abs(v[b, 3 * leg:3 * leg + 3] - Jn @ s["qd"][b, 3 * leg:3 * leg + 3]).max() < 2e-4
+
+
+def test_ik_inverts_fk_and_command_is_jt_f():
+    s = W.make_leg_states(40)
+    J, p, v = G.leg_update(s["q"], s["qd"])
+    c = dict(s, J=J, p=p, v=v, p_des=p)
+    tau, qdes = G.leg_command(c)
+    # computeLegIK (LegController.cpp:255-285) picks the knee branch gamma = atan2(-sqrt(1 - D^2), D) <= 0
+    # and measures the hip angle from -x ("atan2(-pDes[0], ...)"): it is the inverse of the forward
+    # kinematics up to that mirror, FK(IK(p)) = (-p_x, p_y, p_z) -- a quirk of the reference that the
+    # restatement keeps (qDes is computed by updateCommand but not used in the torque law).
+    J2, p2, _ = G.leg_update(qdes, s["qd"])
+    mirror = p.reshape(40, 4, 3) * np.array([-1.0, 1.0, 1.0], np.float32)
+    assert np.abs(p2.reshape(40, 4, 3) - mirror).max() < 2e-5
+    assert (qdes.reshape(40, 4, 3)[:, :, 2] <= 0).all()
+    # torque law in fp64
+    for b in range(0, 40, 5):
+        for leg in range(4):
+            sl = slice(3 * leg, 3 * leg + 3)
+            Jm = J[b, leg].reshape(3, 3).astype(np.float64)
+            ff = (s["force_ff"][b, sl] + s["kp_cart"][b, leg].reshape(3, 3).astype(np.float64) @ (p[b, sl] - p[b, sl])
+                  + s["kd_cart"][b, leg].reshape(3, 3).astype(np.float64) @ (s["v_des"][b, sl].astype(np.float64) - v[b, sl]))
+            ref = s["tau_ff"][b, sl] + Jm.T @ ff + s["kp_joint"] * (0 - s["q"][b, sl]) - s["kd_joint"] * s["qd"][b, sl]
+            assert np.abs(tau[b, sl] - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+
+
+def test_swing_bezier_properties():
+    s = W.make_swing_states(200)
+    p, v, a = G.swing(s["p0"], s["pf"], s["height"], s["phase"], s["swing_time"])
+    # end points and apex
+    z = np.zeros(200, np.float32)
+    o = np.ones(200, np.float32)
+    p_0, v_0, _ = G.swing(s["p0"], s["pf"], s["height"], z, s["swing_time"])
+    p_1, v_1, _ = G.swing(s["p0"], s["pf"], s["height"], o, s["swing_time"])
+    p_h, v_h, _ = G.swing(s["p0"], s["pf"], s["height"], 0.5 * o, s["swing_time"])
+    assert np.array_equal(p_0, s["p0"]) and np.all(v_0 == 0)
+    assert np.abs(p_1 - s["pf"]).max() < 1e-6 and np.all(v_1 == 0)
+    assert np.abs(p_h[:, 2] - (s["p0"][:, 2] + s["height"])).max() < 1e-6 and np.all(v_h[:, 2] == 0)
+    # v is dp/dt, a is dv/dt (fp64 differences of the float curve, away from the apex kink)
+    ok = np.abs(s["phase"] - 0.5) > 0.02
+    ok &= (s["phase"] > 0.02) & (s["phase"] < 0.98)
+    dph = 1e-3
+    pp, vp, _ = G.swing(s["p0"], s["pf"], s["height"], s["phase"] + dph, s["swing_time"])
+    pm, vm, _ = G.swing(s["p0"], s["pf"], s["height"], s["phase"] - dph, s["swing_time"])
+    dt = (2 * dph * s["swing_time"])[:, None]
+    assert np.abs((pp - pm)[ok] / dt[ok] - v[ok]).max() < 2e-2
+    assert np.abs((vp - vm)[ok] / dt[ok] - a[ok]).max() < 2.0

@@ -1,0 +1,114 @@
+"""GPU suite (-m gpu) for the per-tick glue kernels through the C ABI, against the
+float restatement oracle/glue_oracle.c.
+
+Tolerances: the swing-foot Bezier is pure float algebra -> BIT-EXACT.  Leg kinematics / command use
+sinf / cosf / atan2f / sqrtf, whose device (ocml) and host (glibc) implementations may differ by an
+ulp, so those are held to a few float ulps of the quantity's scale:
+    J, p (metres)      <= 3e-7      v = J qd (m/s, |qd| ~ 2)   <= 3e-6
+    tau (N m, forces ~ 100 N)       <= 2e-4 relative to max(1, |tau|)
+    q_des (rad)        <= 5e-6 away from the atan2 / sqrt singularities
+and bit-exact whenever the same J, p, v are fed to both sides (the algebra itself).
+"""
+import numpy as np
+import pytest
+
+from oracle import glue as G
+from quadruped_ctrl_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _mpc(mpc_factory, B):
+    return mpc_factory({"batch": B, "horizon": 10, "dt": 0.026, "mu": 0.4, "f_max": 120.0})
+
+
+@pytest.mark.parametrize("B", [1, 3, 257, 4096])
+def test_leg_kinematics_vs_oracle(B, mpc_factory):
+    import torch
+    m = _mpc(mpc_factory, B)
+    s = W.make_leg_states(B, seed=B)
+    J, p, v = m.leg_kinematics(m._dev32(s["q"]), m._dev32(s["qd"]))
+    torch.cuda.synchronize()
+    Jr, pr, vr = G.leg_update(s["q"], s["qd"])
+    assert np.abs(J.cpu().numpy() - Jr).max() < 3e-7
+    assert np.abs(p.cpu().numpy() - pr).max() < 3e-7
+    assert np.abs(v.cpu().numpy() - vr).max() < 3e-6
+    assert np.all(J.cpu().numpy()[:, :, 0] == 0)         # J(0,0) = 0 exactly
+
+
+@pytest.mark.parametrize("B", [1, 5, 1000])
+def test_leg_torques_vs_oracle(B, mpc_factory):
+    import torch
+    m = _mpc(mpc_factory, B)
+    s = W.make_leg_states(B, seed=10 + B)
+    Jr, pr, vr = G.leg_update(s["q"], s["qd"])
+    host = dict(s, J=Jr, p=pr, v=vr, p_des=pr + s["dp_des"])
+    tau_r, qdes_r = G.leg_command(host)
+    # (a) the algebra: same J, p, v on both sides -> torques bit-exact
+    dev = {k: m._dev32(host[k]) for k in ("tau_ff", "force_ff", "kp_cart", "kd_cart", "p_des", "v_des", "q", "qd", "J", "p", "v")}
+    dev.update(kp_joint=s["kp_joint"], kd_joint=s["kd_joint"])
+    tau, qdes = m.leg_torques(dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(tau.cpu().numpy(), tau_r)
+    assert np.abs(qdes.cpu().numpy() - qdes_r).max() < 5e-6
+    # (b) the chain kinematics -> command entirely on the GPU
+    Jd, pd, vd = m.leg_kinematics(dev["q"], dev["qd"])
+    dev2 = dict(dev, J=Jd, p=pd, v=vd)
+    tau2, _ = m.leg_torques(dev2)
+    torch.cuda.synchronize()
+    t2 = tau2.cpu().numpy()
+    assert (np.abs(t2 - tau_r) <= 2e-4 * np.maximum(1.0, np.abs(tau_r))).all()
+    # (c) optional inputs: NULL feed-forward terms read zero
+    dev3 = dict(dev, tau_ff=None, force_ff=None)
+    tau3, _ = m.leg_torques(dev3)
+    z = np.zeros_like(host["tau_ff"])
+    tau3_r, _ = G.leg_command(dict(host, tau_ff=z, force_ff=z))
+    torch.cuda.synchronize()
+    assert np.array_equal(tau3.cpu().numpy(), tau3_r)
+
+
+def test_leg_torques_consume_the_mpc_forces(mpc_factory):
+    """The consumer chain of get_solution: solve -> f_ff = -rBody f (qmpc_solve_commands) -> stance legs get
+    forceFeedForward = f_ff (ConvexMPCLocomotion.cpp:456) -> tau = J^T f_ff + joint PD (LegController.cpp:134)."""
+    import torch
+    B = 96
+    cmd = W.make_commands(B, horizon=10, seed=21, stand_fraction=0.2, calm=True)
+    m = _mpc(mpc_factory, B)
+    d = m.upload_command(cmd)
+    o = m.alloc_outputs(B, full=False)
+    _, out = m.make_args(m.alloc_record(B), o)
+    f_ff = torch.empty_like(o["grf"])
+    m.solve_commands_async(B, m.make_command_args(d), out, f_ff)
+    s = W.make_leg_states(B, seed=5)
+    q, qd = m._dev32(s["q"]), m._dev32(s["qd"])
+    J, p, v = m.leg_kinematics(q, qd)
+    zero9 = torch.zeros((B, 4, 9), dtype=torch.float32, device=q.device)
+    tau, _ = m.leg_torques({"tau_ff": None, "force_ff": f_ff, "kp_cart": zero9, "kd_cart": zero9, "p_des": p, "v_des": v,
+                            "q": q, "qd": qd, "J": J, "p": p, "v": v, "kp_joint": 0.0, "kd_joint": 0.0})
+    torch.cuda.synchronize()
+    Jn, fn = J.cpu().numpy().reshape(B, 4, 3, 3).astype(np.float64), f_ff.cpu().numpy().reshape(B, 4, 3).astype(np.float64)
+    ref = np.einsum("blji,blj->bli", Jn, fn).reshape(B, 12)          # J^T f per leg
+    assert np.abs(tau.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(ref).max() > 1.0                                       # the MPC forces really arrive
+
+
+@pytest.mark.parametrize("n", [1, 4, 1023, 65536])
+def test_swing_trajectory_bit_exact(n, mpc_factory):
+    import torch
+    m = _mpc(mpc_factory, max(1, (n + 3) // 4))
+    s = W.make_swing_states(n, seed=n)
+    p, v, a = m.swing_trajectory(*(m._dev32(s[k]) for k in ("p0", "pf", "height", "phase", "swing_time")))
+    torch.cuda.synchronize()
+    pr, vr, ar = G.swing(s["p0"], s["pf"], s["height"], s["phase"], s["swing_time"])
+    assert np.array_equal(p.cpu().numpy(), pr)
+    assert np.array_equal(v.cpu().numpy(), vr)
+    assert np.array_equal(a.cpu().numpy(), ar)
+
+
+def test_glue_argument_errors(mpc_factory):
+    import ctypes as C
+    m = _mpc(mpc_factory, 4)
+    assert m.lib.qmpc_leg_kinematics(m.h, 4, None, None, None, None, None, None) == 1
+    assert m.lib.qmpc_swing_trajectory(m.h, 17, *([None] * 9)) == 1       # > 4 * max_batch feet
+    assert m.lib.qmpc_leg_kinematics(m.h, 0, None, None, None, None, None, None) == 1
+    assert m.lib.qmpc_set_leg_geometry(m.h, 0.062, -1.0, 0.195, 0.004) == 1
