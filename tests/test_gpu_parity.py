@@ -834,3 +834,45 @@ def test_empty_batch_and_argument_errors(mpc_factory):
     m.solve_async(8, inp, out)
     torch.cuda.synchronize()
     assert not (o["grf"] == 7.0).all()
+
+
+def test_torch_custom_op(mpc_factory):
+    """torch.ops.qmpc.solve: tensors in, tensors out, current stream, same bits as the C ABI
+    driven through the ctypes binding; no CPU implementation behind it."""
+    import torch
+    import quadruped_ctrl_amd.torch_op as T
+    b = W.make_config(2, batch=300)
+    want = mpc_factory(b).solve(b, full=True)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(b[k])).to(dev) for k in
+         ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights", "alpha", "x_drag")}
+    args = [t[k] for k in ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights", "alpha", "x_drag")]
+    grf, soln, status, iters = torch.ops.qmpc.solve(*args, b["dt"], b["mu"], b["f_max"], True)
+    torch.cuda.synchronize()
+    assert np.array_equal(grf.cpu().numpy(), want["grf"]) and np.array_equal(soln.cpu().numpy(), want["soln"])
+    assert np.array_equal(status.cpu().numpy(), want["status"]) and np.array_equal(iters.cpu().numpy(), want["iters"])
+    # another stream, shared parameters, no full solution
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        a2 = list(args)
+        a2[8], a2[9], a2[10] = t["weights"][0].contiguous(), t["alpha"][:1].contiguous(), t["x_drag"][:1].contiguous()
+        g2, s2, st2, it2 = torch.ops.qmpc.solve(*a2, b["dt"], b["mu"], b["f_max"], False)
+    s.synchronize()
+    assert np.array_equal(g2.cpu().numpy(), want["grf"]) and s2.shape == (0, 120)
+    # a bigger batch than the cached handle grows it; horizon 16 gets its own handle
+    big = W.make_config(1, batch=2048)
+    tb = [torch.from_numpy(np.ascontiguousarray(big[k])).to(dev) for k in
+          ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights", "alpha", "x_drag")]
+    gb = torch.ops.qmpc.solve(*tb, big["dt"], big["mu"], big["f_max"], False)[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(gb.cpu().numpy()[:64], mpc_factory(big).solve(W.shard(big, 0, 32))["grf"])
+    # loud failures: CPU tensors have no kernel, wrong shapes are refused
+    with pytest.raises(Exception):
+        torch.ops.qmpc.solve(*[x.cpu() for x in args], b["dt"], b["mu"], b["f_max"], False)
+    with pytest.raises(Exception):
+        bad = list(args)
+        bad[4] = bad[4][:, :11].contiguous()
+        torch.ops.qmpc.solve(*bad, b["dt"], b["mu"], b["f_max"], False)
+    torch.library.opcheck(torch.ops.qmpc.solve, (*args, b["dt"], b["mu"], b["f_max"], True),
+                          test_utils=("test_schema", "test_faketensor"))
+    T.release_handles()
