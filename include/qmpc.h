@@ -136,6 +136,21 @@ int qmpc_set_max_stance(qmpc_handle h, int max_stance_footsteps);
  * A robot below the bound is still solved correctly.  0 = no hint. */
 int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 
+/* Warm start across MPC cycles (the reference cold-starts every solve,
+ * SolverMPC.cpp:529-541).  ws_dev[max_batch][QMPC_WS_SLOTS] is a DEVICE buffer the caller keeps
+ * between cycles, initialised to -1.  While it is set, every solve (a) reads robot b's previous
+ * working set from row b -- global constraint ids 5 * (4 * step + foot) + type, type 0..3 = the
+ * friction-pyramid rows of f_block (SolverMPC.cpp:366-370), 4 = fz <= f_max; -1 = empty -- slides
+ * it by `shift_steps` horizon steps (1 when the contact table advanced by one MPC step since the
+ * last solve; entries that fall off the front or land on a swing foot-step are discarded), adds
+ * those constraints first without search, drops the ones whose multiplier comes out negative, and
+ * continues with the normal dual active-set iteration; (b) writes the final working set back.
+ * The result is the same unique minimiser as a cold solve (the QP is strictly convex); only the
+ * iteration path is shorter.  Row order must follow the robots (row b belongs to robot b of every
+ * call).  NULL switches warm starting off.  The largest size class (n_r > 128) always starts cold. */
+#define QMPC_WS_SLOTS 64
+int qmpc_set_warm_start(qmpc_handle h, int32_t* ws_dev, int shift_steps);
+
 /* Solve `batch` independent MPC problems.  All pointers are DEVICE pointers
  * valid on the handle's device; the call only enqueues work on `stream`
  * (a hipStream_t, NULL = default stream) and returns; results are readable

@@ -46,6 +46,8 @@ struct qmpc_ctx {
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
+  int32_t* ws = nullptr;  // warm-start buffer (device), see qmpc_set_warm_start
+  int ws_shift = 1;
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
   double* dbg_aux = nullptr;
@@ -107,7 +109,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 7; }
+int qmpc_abi_version(void) { return 8; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -224,6 +226,13 @@ int qmpc_set_min_stance(qmpc_handle c, int min_stance_footsteps) {
   return QMPC_OK;
 }
 
+int qmpc_set_warm_start(qmpc_handle c, int32_t* ws_dev, int shift_steps) {
+  if (!c || shift_steps < 0) return QMPC_ERR_ARG;
+  c->ws = ws_dev;
+  c->ws_shift = shift_steps;
+  return QMPC_OK;
+}
+
 int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_H = H_dev;
@@ -315,6 +324,8 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.ctab = c->d_tables + 3 * h;
   P.max_iter = c->max_iter;
   P.tol = c->tol;
+  P.ws = c->ws;
+  P.ws_shift = c->ws_shift;
   P.dbg_H = c->dbg_H;
   P.dbg_g = c->dbg_g;
   P.dbg_aux = c->dbg_aux;

@@ -13,6 +13,9 @@
 #define QMPC_DEV_ST_FALLBACK 16
 #define QMPC_DEV_ST_NONFINITE 32
 
+// warm start: working-set slots kept per robot between MPC cycles (QMPC_WS_SLOTS of qmpc.h)
+#define QMPC_WS_STRIDE 64
+
 // leading dimension of the debug dump (largest padded size, 3 * 64)
 #define QMPC_DBG_LD 192
 
@@ -49,6 +52,11 @@ struct QmpcParams {
   // solver settings
   int max_iter;
   double tol;
+  // warm start (nullptr = cold): [batch][QMPC_WS_STRIDE] working set of the previous cycle as global
+  // constraint ids 5 * (4 step + foot) + type, -1 = empty; read slid by ws_shift horizon steps, rewritten
+  // with this cycle's final working set
+  int32_t* ws;
+  int ws_shift;
   // work lists: robots handed from one size class to the next
   const int* list;   // nullptr: robot = blockIdx.x
   int* count;        // entries in `list`

@@ -277,6 +277,7 @@ struct Smem {
   QmpcParams par;  // kernel parameters parked in LDS (keeps ~45 uniforms out of SGPRs)
   double fmaxk[64];
   unsigned char sidx[64];
+  unsigned char kslot[64];  // foot-step k -> stance slot (0xff = swing): inverse of sidx, for the warm start
   int nst, status;
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   // ---- phase-local storage
@@ -480,6 +481,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       S.sidx[pos] = (unsigned char)tid;
       S.fmaxk[pos] = (double)fm;
     }
+    S.kslot[tid] = st ? (unsigned char)pos : (unsigned char)0xff;
     if (tid == 0) {
       S.nst = __popcll(mask);
       S.status = 0;
@@ -607,6 +609,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         if (P.iters) P.iters[rid] = 0;
         if (cmdm) cmd_finish_state();
       }
+      if (P.ws && tid < QMPC_WS_STRIDE) P.ws[(size_t)rid * QMPC_WS_STRIDE + tid] = -1;
     } else if (P.next_list) {
       if (tid == 0) {
         const int slot = atomicAdd(P.next_count, 1);
@@ -1112,6 +1115,24 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       double lam = 0.0;    // ... and its multiplier
       int khw = 0, status = 0, neva = 0, nevd = 0;
       bool need_p = true;
+      // ---- warm start (qmpc_set_warm_start): the previous cycle's working set, slid by `ws_shift`
+      // horizon steps and mapped onto this cycle's stance slots, one candidate per lane.  The
+      // candidates are ADDED FIRST, without search or ratio test (a full step onto each, whatever the
+      // sign of the step): that lands on the minimiser of the equality-constrained problem on that
+      // set.  Candidates whose multiplier comes out negative are then dropped one by one; what
+      // remains is a genuine Goldfarb-Idnani state (x optimal on W, multipliers >= 0) and the normal
+      // iteration takes over.  The answer is the same unique minimiser; only the path is shorter.
+      int cand = -1;
+      if (P.ws && lane < KS) {
+        const int eg = P.ws[(size_t)rid * QMPC_WS_STRIDE + lane];  // global id 5 * (4 step + foot) + type
+        const int kg = (eg >= 0 ? eg / 5 : 0) - 4 * P.ws_shift;
+        if (eg >= 0 && kg >= 0 && kg < nfs) {
+          const int sl = S.kslot[kg];
+          if (sl != 0xff) cand = 5 * sl + (eg - 5 * (eg / 5));
+        }
+      }
+      unsigned long long cmask = __ballot(cand >= 0);
+      bool forced = false, fixneg = (cmask != 0ull);
       int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
       double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
       int rbl[RE];
@@ -1145,6 +1166,68 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         y = __builtin_fma(0.5 * y, e, y);
         return y;
       };
+      // Remove working-set slot l: one drop event.  u = N*_l (index-major lanes), sc = S^-1[:, l]
+      // (slot lanes), gamma = S^-1[l][l].  With `repair` (warm start) the iterate also moves to the
+      // minimiser of the problem WITHOUT that constraint: x -= (lam_l / gamma) u, lam -= (lam_l / gamma) sc.
+      // Returns false when the projected inverse has lost definiteness numerically (retry is set).
+      auto drop_slot = [&](int l, bool repair) __attribute__((always_inline)) {
+        double u[RE], sc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) u[q] = 0.0;
+        auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
+          constexpr int DIR = decltype(dirc)::value;
+#pragma unroll 1
+          for (int t0 = 0; t0 < cnt; t0 += 4) {
+            const double* ev = pool + (base + DIR * t0) * EV;
+            double gll[4], zl[4][RE], gw[4];
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+              const double* eu = ev + DIR * u4 * EV;
+              gll[u4] = eu[NPE + l];
+#pragma unroll
+              for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
+              gw[u4] = eu[gl_off];
+            }
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+#pragma unroll
+              for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
+              sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
+            }
+          }
+        };
+        dacc(std::integral_constant<int, 1>{}, 0, neva);
+        if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
+        const double gamma = readlane_f64(sc, l);
+        if (uni(!(gamma > 0.0))) {
+          retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
+          return false;
+        }
+        if (repair) {
+          const double coef = readlane_f64(lam, l) * fast_rcp(gamma);
+#pragma unroll
+          for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(-coef, u[q], xv[q]);
+          lam = __builtin_fma(-coef, sc, lam);
+        }
+        const double sg = rsqrt_full(gamma);
+        const int de = __builtin_amdgcn_readlane(wcid, l);
+        double* en = pool + (KEV - 1 - nevd) * EV;
+#pragma unroll
+        for (int q = 0; q < RE; ++q)
+          if (zw[q]) en[zo[q]] = u[q] * sg;
+        if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
+        // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
+        if (lane < neva) pool[lane * EV + NPE + l] = 0.0;
+        if (lane < nevd) pool[(KEV - 1 - lane) * EV + NPE + l] = 0.0;
+        if (lane == l) {
+          wcid = -1;
+          lam = 0.0;
+        }
+        if (lane == de / 5) amask &= ~(1u << (de % 5));
+        nevd += 1;
+        __builtin_amdgcn_wave_barrier();
+        return true;
+      };
       __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);  // the serial part of the workgroup: win issue arbitration
 
       while (true) {
@@ -1159,6 +1242,35 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         pty = __builtin_amdgcn_readfirstlane(pty);
         pj1 = __builtin_amdgcn_readfirstlane(pj1);
         pj2 = __builtin_amdgcn_readfirstlane(pj2);
+        if (uni(need_p) && cmask != 0ull) {
+          // ---- warm start: next candidate of the previous working set, forced
+          const int cl = __ffsll((long long)cmask) - 1;
+          cmask &= cmask - 1ull;
+          p_e = __builtin_amdgcn_readlane(cand, cl);
+          psl = p_e / 5;
+          pty = p_e - 5 * psl;
+          con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+          p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
+          lp = 0.0;
+          need_p = false;
+          forced = true;
+        } else if (uni(need_p) && fixneg) {
+          // ---- warm start, second phase: a candidate whose multiplier is negative does not belong to
+          // the working set -- remove it (one drop event) and move to the minimiser without it
+          const unsigned long long nm = __ballot(wcid >= 0 && lam < 0.0);
+          if (nm == 0ull) {
+            fixneg = false;
+            continue;
+          }
+          if (((neva + 3) & ~3) + ((nevd + 4) & ~3) > KEV || iters >= max_iter) {
+            retry = true;  // no room to repair the guess: start over, cold, with the other engine
+            break;
+          }
+          const int l = __ffsll((long long)nm) - 1;
+          if (!drop_slot(l, true)) break;
+          iters += 1;
+          continue;
+        }
         if (uni(need_p)) {
           // ---- most violated constraint outside the working set (normalised), or done
           unsigned key = 0;
@@ -1190,6 +1302,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
           lp = 0.0;
           need_p = false;
+          forced = false;
         }
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
         // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
@@ -1233,15 +1346,19 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
         const bool dep = uni(!(delta > 1e-11 * cn));
+        if (forced && dep) {  // a candidate that depends on the ones already added: skip it
+          need_p = true;
+          continue;
+        }
         const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
         double ratio = __builtin_inf();
-        if (wcid >= 0 && rw > 0.0) {
+        if (!forced && wcid >= 0 && rw > 0.0) {
           const double qv = lam * fast_rcp(rw);
           ratio = qv > 0.0 ? qv : 0.0;
         }
         double t1 = __builtin_inf();
         int l = -1;
-        if (khw > 0) {
+        if (khw > 0 && !forced) {
           t1 = wave_min_pos_f64(ratio);
           if (uni(t1 < __builtin_inf())) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
         }
@@ -1285,55 +1402,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             retry = true;
             break;
           }
-          // u = N*_l (index-major lanes), sc = S^-1[:, l] (slot lanes)
-          double u[RE], sc = 0.0;
-#pragma unroll
-          for (int q = 0; q < RE; ++q) u[q] = 0.0;
-          auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
-            constexpr int DIR = decltype(dirc)::value;
-#pragma unroll 1
-            for (int t0 = 0; t0 < cnt; t0 += 4) {
-              const double* ev = pool + (base + DIR * t0) * EV;
-              double gll[4], zl[4][RE], gw[4];
-#pragma unroll
-              for (int u4 = 0; u4 < 4; ++u4) {
-                const double* eu = ev + DIR * u4 * EV;
-                gll[u4] = eu[NPE + l];
-#pragma unroll
-                for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
-                gw[u4] = eu[gl_off];
-              }
-#pragma unroll
-              for (int u4 = 0; u4 < 4; ++u4) {
-#pragma unroll
-                for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
-                sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
-              }
-            }
-          };
-          dacc(std::integral_constant<int, 1>{}, 0, neva);
-          if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
-          const double gamma = readlane_f64(sc, l);
-          if (uni(!(gamma > 0.0))) {
-            retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
-            break;
-          }
-          const double sg = rsqrt_full(gamma);
-          const int de = __builtin_amdgcn_readlane(wcid, l);
-          double* en = pool + (KEV - 1 - nevd) * EV;
-#pragma unroll
-          for (int q = 0; q < RE; ++q)
-            if (zw[q]) en[zo[q]] = u[q] * sg;
-          if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
-          // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
-          if (lane < neva) pool[lane * EV + NPE + l] = 0.0;
-          if (lane < nevd) pool[(KEV - 1 - lane) * EV + NPE + l] = 0.0;
-          if (lane == l) {
-            wcid = -1;
-            lam = 0.0;
-          }
-          if (lane == de / 5) amask &= ~(1u << (de % 5));
-          nevd += 1;
+          if (!drop_slot(l, false)) break;
         }
         __builtin_amdgcn_wave_barrier();
         if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
@@ -1368,6 +1437,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (P.iters) P.iters[rid] = iters;
           if (cmdm) cmd_finish_state();
         }
+        if (P.ws)  // the final working set, as global ids, for the next cycle's warm start
+          P.ws[(size_t)rid * QMPC_WS_STRIDE + lane] =
+              (lane < KS && wcid >= 0 && !dead) ? 5 * (int)S.sidx[wcid / 5] + (wcid % 5) : -1;
         if (cmdm && P.f_ff) {
           float* fb = reinterpret_cast<float*>(Sb.D);  // diag(H^-1) is dead now
           if (lane < 12) fb[lane] = 0.f;
@@ -1764,6 +1836,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       if (P.iters) P.iters[rid] = iters;
       if (cmdm) cmd_finish_state();
     }
+    if (P.ws)  // (this engine always starts cold; it still leaves its working set for the next cycle)
+      P.ws[(size_t)rid * QMPC_WS_STRIDE + lane] =
+          (wcid[0] >= 0 && !dead) ? 5 * (int)S.sidx[wcid[0] / 5] + (wcid[0] % 5) : -1;
     if (cmdm && P.f_ff) {
       float* fb = reinterpret_cast<float*>(Sb.D);  // not used by this engine
       if (lane < 12) fb[lane] = 0.f;

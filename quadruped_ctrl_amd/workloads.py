@@ -246,3 +246,91 @@ def make_swing_states(n, seed=4):
     phase[:3] = [0.0, 0.5, 1.0][:min(3, n)]
     return {"p0": p0.astype(f32), "pf": pf.astype(f32), "height": rng.uniform(0.06, 0.1, n).astype(f32),
             "phase": phase.astype(f32), "swing_time": (0.026 * rng.integers(5, 10, n)).astype(f32)}
+
+
+class Rollout:
+    """Closed-loop sliding-window rollout of B robots for the warm-start measurements:
+    every MPC cycle the contact table advances by one step (OffsetDurationGait iteration + 1,
+    Gait.cpp:187-193), the single-rigid-body state is integrated over dtMPC with the first-step
+    forces the solver returned (the model of SolverMPC.cpp:235-254, explicit Euler, fp64 on the host),
+    stance feet stay where they are and feet that lift off are re-placed under their hips.  Host-side
+    test / bench scaffolding: it only PRODUCES input records, all solving is the GPU's."""
+
+    HIP = np.array([[.19, -.111], [.19, .111], [-.19, -.111], [-.19, .111]])
+
+    def __init__(self, batch, horizon=10, gait="trot", seed=0, v_des=0.5):
+        rng = np.random.default_rng(SEED0 + 5000 + seed)
+        self.B, self.h = batch, horizon
+        h = horizon
+        table = {"trot": ((0, h // 2, h // 2, 0), (h // 2,) * 4),
+                 "bound": ((h // 2, h // 2, 0, 0), (max(h // 2 - 1, 1),) * 4),
+                 "pace": ((h // 2, 0, h // 2, 0), (h // 2,) * 4),
+                 "stand": ((0, 0, 0, 0), (h,) * 4)}
+        names = [gait] * batch if gait != "mixed" else list(rng.choice(["trot", "bound", "pace"], batch))
+        self.off = np.array([table[n][0] for n in names])
+        self.dur = np.array([table[n][1] for n in names])
+        self.it = rng.integers(0, h, batch)
+        self.p = np.array([0, 0, 0.29]) + rng.normal(0, 0.01, (batch, 3))
+        self.v = np.zeros((batch, 3))
+        self.v[:, 0] = (0.0 if gait == "stand" else v_des) + rng.normal(0, 0.05, batch)
+        self.rpy = rng.normal(0, 0.03, (batch, 3))
+        self.w = rng.normal(0, 0.1, (batch, 3))
+        self.vdes = np.zeros((batch, 2))
+        self.vdes[:, 0] = 0.0 if gait == "stand" else v_des
+        self.yaw_rate = rng.normal(0, 0.2, batch) * (0.0 if gait == "stand" else 1.0)
+        self.feet = np.zeros((batch, 4, 3))
+        self._place(np.ones((batch, 4), bool))
+        self.feet[:, :, :2] += rng.normal(0, 0.01, (batch, 4, 2))
+
+    def _place(self, mask):
+        cy, sy = np.cos(self.rpy[:, 2]), np.sin(self.rpy[:, 2])
+        hx = cy[:, None] * self.HIP[None, :, 0] - sy[:, None] * self.HIP[None, :, 1]
+        hy = sy[:, None] * self.HIP[None, :, 0] + cy[:, None] * self.HIP[None, :, 1]
+        tgt = np.stack([self.p[:, None, 0] + hx + 0.5 * 0.13 * self.v[:, None, 0],
+                        self.p[:, None, 1] + hy + 0.5 * 0.13 * self.v[:, None, 1],
+                        np.zeros_like(hx)], -1)
+        self.feet[mask] = tgt[mask]
+
+    def contact_table(self):
+        g = np.zeros((self.B, 4 * self.h), np.uint8)
+        for i in range(self.B):
+            g[i] = mpc_table(self.h, tuple(self.off[i]), tuple(self.dur[i]), int(self.it[i]))
+        return g
+
+    def record(self):
+        """The update_data_t record of this cycle (workloads layout)."""
+        B, h = self.B, self.h
+        f32 = np.float32
+        q = _quat_from_rpy(self.rpy)
+        traj = np.zeros((B, h, 12))
+        k = np.arange(h)[None]
+        traj[:, :, 2] = self.rpy[:, 2:3] + self.yaw_rate[:, None] * DT_MPC * k
+        traj[:, :, 3] = self.p[:, 0:1] + self.vdes[:, 0:1] * DT_MPC * k
+        traj[:, :, 4] = self.p[:, 1:2] + self.vdes[:, 1:2] * DT_MPC * k
+        traj[:, :, 5] = 0.29
+        traj[:, :, 8] = self.yaw_rate[:, None]
+        traj[:, :, 9] = self.vdes[:, 0:1]
+        traj[:, :, 10] = self.vdes[:, 1:2]
+        r = (self.feet - self.p[:, None, :]).transpose(0, 2, 1).reshape(B, 12)      # axis-major
+        d = dict(p=self.p.astype(f32), v=self.v.astype(f32), q=q.astype(f32), w=self.w.astype(f32),
+                 r=r.astype(f32), yaw=self.rpy[:, 2].astype(f32), traj=traj.reshape(B, 12 * h).astype(f32))
+        return _finish(d, B, h, self.contact_table())
+
+    def advance(self, grf):
+        """Integrate one MPC step with the first-step forces grf[B,12] (world frame, foot-major)."""
+        f = np.asarray(grf, np.float64).reshape(self.B, 4, 3)
+        m, ib = 9.0, np.array([.07, .26, .242])
+        cy, sy = np.cos(self.rpy[:, 2]), np.sin(self.rpy[:, 2])
+        R = np.zeros((self.B, 3, 3))
+        R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = cy, -sy, sy, cy, 1.0
+        Iinv = np.einsum("bij,j,bkj->bik", R, 1.0 / ib, R)
+        tau = np.cross(self.feet - self.p[:, None, :], f).sum(1)
+        acc = f.sum(1) / m + np.array([0, 0, -9.8])
+        self.p = self.p + self.v * DT_MPC
+        self.v = self.v + acc * DT_MPC
+        self.rpy = self.rpy + np.einsum("bji,bj->bi", R, self.w) * DT_MPC
+        self.w = self.w + np.einsum("bij,bj->bi", Iinv, tau) * DT_MPC
+        before = self.contact_table()[:, :4] != 0
+        self.it = (self.it + 1) % self.h
+        after = self.contact_table()[:, :4] != 0
+        self._place(before & ~after)          # feet that just lifted off: re-placed under the hips

@@ -876,3 +876,48 @@ def test_torch_custom_op(mpc_factory):
     torch.library.opcheck(torch.ops.qmpc.solve, (*args, b["dt"], b["mu"], b["f_max"], True),
                           test_utils=("test_schema", "test_faketensor"))
     T.release_handles()
+
+
+@pytest.mark.parametrize("gait,h", [("trot", 10), ("mixed", 10), ("stand", 10), ("trot", 16)])
+def test_warm_start_rollout_same_answer(gait, h, mpc_factory):
+    """qmpc_set_warm_start over a closed-loop sliding-window rollout: every cycle the warm-started solve
+    returns the cold solve's minimiser (<= 1e-9 relative: the QP is strictly convex, only the path differs),
+    the working-set buffer round-trips, and switching warm start off restores the cold bits."""
+    import torch
+    B = 96
+    ro = W.Rollout(B, h, gait, seed=3)
+    b = ro.record()
+    cold, warm = mpc_factory(b), mpc_factory(b)
+    ws = warm.warm_start(B, shift_steps=1)
+    assert (ws == -1).all()
+    used = 0
+    for c in range(8):
+        b = ro.record()
+        rc = cold.solve(b, full=True)
+        rw = warm.solve(b, full=True)
+        assert ((rc["status"] & 47) == 0).all() and ((rw["status"] & 47) == 0).all()
+        err = np.abs(rw["soln"] - rc["soln"]).max(1) / np.maximum(np.abs(rc["soln"]).max(1), 1.0)
+        assert err.max() < 1e-9, (c, err.max())
+        w = ws.cpu().numpy()
+        nact = (w >= 0).sum(1)
+        assert (w < 20 * h).all()
+        if c > 0:
+            used += int(nact.sum())
+        # the buffer holds exactly the constraints that are active at the solution (global ids)
+        f = rc["soln"].reshape(B, 4 * h, 3)
+        mi = 1.0 / 0.4
+        for i in range(0, B, 17):
+            act = set()
+            for k in range(4 * h):
+                if not b["gait"][i, k]:
+                    continue
+                fx, fy, fz = f[i, k]
+                rows = [mi * fx + fz, -mi * fx + fz, mi * fy + fz, -mi * fy + fz, b["f_max"] - fz]
+                act |= {5 * k + t for t in range(5) if abs(rows[t]) < 1e-7}
+            got = set(int(x) for x in w[i] if x >= 0)
+            assert got <= act          # (a degenerate apex may leave a dependent active row out of the working set)
+        ro.advance(rc["grf"])
+    assert used > 0
+    warm.warm_start(None)
+    b = ro.record()
+    assert np.array_equal(warm.solve(b, full=True)["soln"], cold.solve(b, full=True)["soln"])
