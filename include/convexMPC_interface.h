@@ -33,8 +33,8 @@ QMPC_C_LINKAGE void update_problem_data(double* p, double* v, double* q, double*
                                         double* state_trajectory, double alpha, int* gait);
 /* reference :42  q_soln[index], index < 12*horizon; 0.0 before the first solve */
 QMPC_C_LINKAGE double get_solution(int index);
-/* reference :43  JCQP knobs: accepted and recorded; max_iter caps the
- * active-set iterations, the rest have no meaning for the exact solve */
+/* reference :43  use_jcqp = 0: exact solve, max_iter caps the active-set iterations; use_jcqp = 1 / 2:
+ * the reference's JCQP/ADMM alternate with these very knobs (qmpc_settings_jcqp) */
 QMPC_C_LINKAGE void update_solver_settings(int max_iter, double rho, double sigma,
                                            double solver_alpha, double terminate,
                                            double use_jcqp);
@@ -49,9 +49,8 @@ void update_x_drag(float x_drag);
 #endif
 
 /* status bits (QMPC_ST_* of qmpc.h) of the most recent solve; -1 = never solved.
- * QMPC_SHIM_ST_JCQP_IGNORED is set next to them while update_solver_settings' use_jcqp is
- * non-zero: the reference would then run its approximate ADMM alternate
- * (SolverMPC.cpp:407-421, terminate = 0.1); this library returns the exact minimiser. */
+ * QMPC_SHIM_ST_JCQP_IGNORED is set next to them when update_solver_settings' use_jcqp is a value
+ * other than 0, 1 or 2 (nothing to select: the exact solve ran). */
 #define QMPC_SHIM_ST_JCQP_IGNORED 256
 QMPC_C_LINKAGE int qmpc_shim_last_status(void);
 /* active-set iterations of the most recent solve */

@@ -123,6 +123,20 @@ int qmpc_set_robot(qmpc_handle h, double mass, const double ibody_diag[3],
  * SolverMPC.cpp:435) and the constraint-violation tolerance [N]. */
 int qmpc_settings(qmpc_handle h, int max_iter, double tol);
 
+/* The reference's alternate solver: update_solver_settings(..., use_jcqp) with
+ * use_jcqp = 1 or 2 makes solve_mpc run JCQP's QpProblem<double>::runFromDense
+ * (src/JCQP/QpProblem.cpp:178-269) -- an OSQP-style ADMM from a cold start, stopped when
+ * (|A x - z|_inf + |P x + q + A^T y|_inf) / 4 < terminate (checked every 10 iterations) or after
+ * max_iter iterations -- on the full 12h-variable problem (1, SolverMPC.cpp:400-414) or on the
+ * swing-eliminated one (2, :558-610).  Its result is an APPROXIMATION of the minimiser (about 1e-3
+ * relative with the caller's settings rho = 1e-7, sigma = 1e-8, alpha = 1.5, terminate = 0.1,
+ * ConvexMPCLocomotion.cpp:644-648).  With use_jcqp != 0 qmpc_solve / qmpc_solve_host reproduce THAT
+ * iteration on the GPU (same updates, same stopping rule; iters = ADMM iterations, QMPC_ST_MAXITER when
+ * the residual test never passed); use_jcqp = 0 (default) is the exact active-set solve, which is what
+ * the reference's qpOASES path returns.  qmpc_solve_commands always solves exactly. */
+int qmpc_settings_jcqp(qmpc_handle h, int use_jcqp, int max_iter, double rho, double sigma,
+                       double solver_alpha, double terminate);
+
 /* Optional size hint.  The kernels are specialised by reduced problem size
  * n_r = 3 * (stance foot-steps in the horizon) <= 64 / 96 / 128 / 192; without a
  * hint every class that the horizon allows is launched (the unused ones exit

@@ -17,6 +17,7 @@ struct ShimState {
   float x_drag = 0.f;          // update.x_drag
   int max_iter = 1000;
   double use_jcqp = 0.0;       // update.use_jcqp (convexMPC_interface.cpp:118)
+  double rho = 1e-7, sigma = 1e-8, alpha = 1.5, terminate = 0.1;  // update.rho ... (:113-117)
   std::vector<double> q_soln;  // SolverMPC.cpp:45
   int status = -1, iters = 0;
 } g;
@@ -50,15 +51,18 @@ void solve_floats(const float* p, const float* v, const float* q, const float* w
   g.q_soln.assign(12 * h, 0.0);
   qmpc_outputs out;
   out.grf = grf; out.soln = g.q_soln.data(); out.status = &st; out.iters = &it;
+  // use_jcqp = 1 / 2: the reference's JCQP/ADMM alternate (SolverMPC.cpp:400-414, :558-610), reproduced
+  // on the GPU; otherwise the exact solve
+  const int mode = (g.use_jcqp == 1.0) ? 1 : (g.use_jcqp == 2.0 ? 2 : 0);
+  qmpc_settings_jcqp(g.h, mode, g.max_iter, g.rho, g.sigma, g.alpha, g.terminate);
   const int rc = qmpc_solve_host(g.h, 1, &in, &out);
   if (rc != QMPC_OK) {
     std::fprintf(stderr, "[qmpc shim] solve failed rc=%d %s\n", rc, qmpc_last_error(g.h));
     return;
   }
-  // use_jcqp in {1, 2} asks the reference for its ADMM alternate (SolverMPC.cpp:407-421), an
-  // approximate solve that stops at residual 0.1.  This library always returns the exact minimiser
-  // (what qpOASES returns, and what that ADMM converges to); the request is reported, not dropped
-  g.status = st | (g.use_jcqp != 0.0 ? QMPC_SHIM_ST_JCQP_IGNORED : 0);
+  // (a use_jcqp value other than 0, 1, 2 selects nothing in the reference either -- the exact solve
+  //  runs -- and is reported)
+  g.status = st | ((g.use_jcqp != 0.0 && g.use_jcqp != 1.0 && g.use_jcqp != 2.0) ? QMPC_SHIM_ST_JCQP_IGNORED : 0);
   g.iters = it;
   if (st & QMPC_ST_ERROR_MASK) std::printf("failed to solve! (status bits %d)\n", st);  // SolverMPC.cpp:541
   g.has_solved = true;
@@ -81,8 +85,13 @@ void setup_problem(double dt, int horizon, double mu, double f_max) {
   qmpc_settings(g.h, g.max_iter, 1e-9);
 }
 
-void update_solver_settings(int max_iter, double, double, double, double, double use_jcqp) {
+void update_solver_settings(int max_iter, double rho, double sigma, double solver_alpha, double terminate,
+                            double use_jcqp) {
   g.use_jcqp = use_jcqp;
+  g.rho = rho;
+  g.sigma = sigma;
+  g.alpha = solver_alpha;
+  g.terminate = terminate;
   // the reference's active path caps qpOASES at nWSR = 100 regardless of this
   // value (SolverMPC.cpp:435); max_iter (10000 in the caller) bounds ours.
   g.max_iter = max_iter > 0 ? max_iter : 1000;

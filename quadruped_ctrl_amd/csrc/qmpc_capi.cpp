@@ -46,6 +46,8 @@ struct qmpc_ctx {
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
+  int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
+  double admm_rho = 1e-7, admm_sigma = 1e-8, admm_alpha = 1.5, admm_term = 0.1;
   int32_t* ws = nullptr;  // warm-start buffer (device), see qmpc_set_warm_start
   int ws_shift = 1;
   double* dbg_H = nullptr;
@@ -109,7 +111,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 8; }
+int qmpc_abi_version(void) { return 9; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -226,6 +228,22 @@ int qmpc_set_min_stance(qmpc_handle c, int min_stance_footsteps) {
   return QMPC_OK;
 }
 
+int qmpc_settings_jcqp(qmpc_handle c, int use_jcqp, int max_iter, double rho, double sigma, double solver_alpha,
+                       double terminate) {
+  if (!c || use_jcqp < 0 || use_jcqp > 2) return QMPC_ERR_ARG;
+  if (use_jcqp && (max_iter <= 0 || !(rho > 0) || !(sigma >= 0) || !(solver_alpha > 0) || !(terminate >= 0)))
+    return QMPC_ERR_ARG;
+  c->admm_mode = use_jcqp;
+  if (use_jcqp) {
+    c->admm_max_iter = max_iter;
+    c->admm_rho = rho;
+    c->admm_sigma = sigma;
+    c->admm_alpha = solver_alpha;
+    c->admm_term = terminate;
+  }
+  return QMPC_OK;
+}
+
 int qmpc_set_warm_start(qmpc_handle c, int32_t* ws_dev, int shift_steps) {
   if (!c || shift_steps < 0) return QMPC_ERR_ARG;
   c->ws = ws_dev;
@@ -326,6 +344,14 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.tol = c->tol;
   P.ws = c->ws;
   P.ws_shift = c->ws_shift;
+  if (c->admm_mode && in) {  // (record mode only: the command mode always solves exactly)
+    P.admm_mode = c->admm_mode;
+    P.admm_max_iter = c->admm_max_iter;
+    P.admm_rho = c->admm_rho;
+    P.admm_sigma = c->admm_sigma;
+    P.admm_alpha = c->admm_alpha;
+    P.admm_term = c->admm_term;
+  }
   P.dbg_H = c->dbg_H;
   P.dbg_g = c->dbg_g;
   P.dbg_aux = c->dbg_aux;
@@ -343,7 +369,8 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   // a caller that knows its gaits can bound the reduced size (qmpc_set_max_stance):
   // larger classes are then not even launched; violators are flagged WS_FULL
   int nclass_eff = nclass;
-  if (c->max_stance > 0) {
+  const bool full_problem = (P.admm_mode == 1);  // every foot-step is a variable block: n_r = 12 h for all robots
+  if (c->max_stance > 0 && !full_problem) {
     const int nb = 3 * c->max_stance;
     int hc = 4;
     for (int k = 0; k < 4; ++k)
@@ -356,7 +383,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   int* cnt_next = c->d_counts + 4 * (set ^ 1u); // cleared by this call's first kernel
   // ... and with a lower bound the classes that are too small for every robot are skipped
   int k0 = 0;
-  while (k0 + 1 < nclass_eff && 3 * c->min_stance > rows[k0]) ++k0;
+  while (k0 + 1 < nclass_eff && 3 * (full_problem ? 4 * h : c->min_stance) > rows[k0]) ++k0;
   for (int k = k0; k < nclass_eff; ++k) {
     P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
     P.count = k > k0 ? cnt + (k - 1) : nullptr;

@@ -52,6 +52,10 @@ struct QmpcParams {
   // solver settings
   int max_iter;
   double tol;
+  // JCQP alternate (src/JCQP/QpProblem.cpp:178-269; 0 = off -> exact active-set solve): use_jcqp value
+  // (1 = full problem, 2 = swing-eliminated) and the caller's settings (ConvexMPCLocomotion.cpp:644-648)
+  int admm_mode, admm_max_iter;
+  double admm_rho, admm_sigma, admm_alpha, admm_term;
   // warm start (nullptr = cold): [batch][QMPC_WS_STRIDE] working set of the previous cycle as global
   // constraint ids 5 * (4 step + foot) + type, -1 = empty; read slid by ws_shift horizon steps, rewritten
   // with this cycle's final working set

@@ -91,6 +91,15 @@ __device__ __forceinline__ double wave_min_pos_f64(double x) {
   const unsigned mlo = wave_min_u32(hi == mhi ? lo : ~0u);
   return __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
 }
+// max over the wave of NON-NEGATIVE doubles: the min reduction on the bitwise complement (larger
+// value <=> smaller complement)
+__device__ __forceinline__ double wave_max_pos_f64(double x) {
+  const unsigned long long v = ~(unsigned long long)__double_as_longlong(x);
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mhi = wave_min_u32(hi);
+  const unsigned mlo = wave_min_u32(hi == mhi ? lo : ~0u);
+  return __longlong_as_double((long long)~(((unsigned long long)mhi << 32) | mlo));
+}
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(x);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
@@ -330,7 +339,7 @@ struct Smem {
 // sum of rank-1 events; fastest, capacity-limited by the LDS pool), false = the
 // Schur form that never overflows.  Both are run by wave 0 alone.  Returns true
 // when the robot must be re-run with the other engine.
-template <int RB, bool V5, bool CMD>
+template <int RB, bool V5, bool CMD, bool ADMM = false>
 __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
@@ -474,7 +483,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   // ---- stance list
   if (tid < WAVE) {
     const float fm = (float)g_gait * (float)PK.f_max;  // :361
-    const bool st = !(fm < 0.01f && fm > -.01f);       // :64-67
+    // (use_jcqp == 1 hands JCQP the FULL problem, swing foot-steps included with u = 0: SolverMPC.cpp:400-407)
+    const bool st = (ADMM && PK.admm_mode == 1) ? (tid < nfs) : !(fm < 0.01f && fm > -.01f);  // :64-67
     const unsigned long long mask = __ballot(st);
     const int pos = __popcll(mask & ((1ull << tid) - 1ull));
     if (st) {
@@ -711,6 +721,15 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     const int si = ki >> 2;
     const int u = 3 * (ki & 3) + ai;
     const double dm2 = x_drag * inv_m * inv_m;
+    // JCQP alternate: A^T R A is DIAGONAL for the friction block (its columns are orthogonal):
+    // diag(2 rho_inf / mu^2, 2 rho_inf / mu^2, 4 rho_inf + rho_4) per foot-step, rho_inf for the four rows
+    // whose upper bound is BIG_NUMBER (QpProblem.cpp:278-280), rho_4 for fz <= f_max (equality when u = 0)
+    double admm_diag = 0.0;
+    if constexpr (ADMM) {
+      const double fk = rowok ? S.fmaxk[(i / 3) & 63] : 1.0;
+      const double rho4 = (__builtin_fabs(fk) < 1e-10) ? P.admm_rho * 1e3 : (fk > 1e10 ? 1e-6 : P.admm_rho);
+      admm_diag = P.admm_sigma + ((ai < 2) ? 2.0 * 1e-6 * P.mu_inv * P.mu_inv : 4.0 * 1e-6 + rho4);
+    }
     // the CW columns of this thread walk at most CW/3 + 2 stance slots: fetch
     // their foot-step ids in one batch, then the table / E loads in groups of 4
     constexpr int NSL = CW / 3 + 2;
@@ -781,7 +800,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) {
       const int j = c * CW + jj;
-      const double v = 2.0 * (a[jj] + ((i == j) ? alpha : 0.0));
+      double v = 2.0 * (a[jj] + ((i == j) ? alpha : 0.0));
+      if constexpr (ADMM) v += (i == j) ? admm_diag : 0.0;  // the KKT matrix reduced to the x block
       a[jj] = (rowok && j < n) ? v : ((i == j) ? 1.0 : 0.0);  // identity padding
     }
   }
@@ -1034,6 +1054,16 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       if (j < n) xv[q] = Sw.part[0][j] + Sw.part[1][j] + Sw.part[2][j] + Sw.part[3][j];
     }
   }
+  double gq[RE];  // ADMM engine lane: gradient q[lane + 64 q]
+#pragma unroll
+  for (int q = 0; q < RE; ++q) gq[q] = 0.0;
+  if constexpr (ADMM) {
+    if (engine) {
+#pragma unroll
+      for (int q = 0; q < RE; ++q)
+        if (lane + 64 * q < n) gq[q] = Sw.g[lane + 64 * q];
+    }
+  }
   const double fmx = (engine && lane < nst) ? S.fmaxk[lane] : 0.0;  // f_max of stance slot `lane`
   __syncthreads();  // sweep storage (and the assembly storage under it) is dead: Slv may overwrite it
   if (i < n) {
@@ -1090,7 +1120,159 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   // back (so neither loop needs a sign), rows in between stay zero.
   int iters = 0;
   bool retry = false;
-  if constexpr (V5) {
+  if constexpr (ADMM) {
+    // ---------------------------------------------------------- stage 5 (JCQP alternate)
+    // QpProblem<double>::runFromDense (src/JCQP/QpProblem.cpp:178-269): OSQP-style ADMM from a cold start
+    // with the constant KKT matrix [[P + sigma I, A^T], [A, -R^-1]].  Eliminating the constraint block,
+    //   (P + sigma I + A^T R A) x~ = sigma x - q + A^T (R z - y),    z~ = A x~,
+    // and A^T R A is diagonal here, so the matrix swept above IS that system's and one iteration is one
+    // mat-vec with its explicit inverse (packed in LDS) plus element-wise updates of the five rows of
+    // every foot-step: x <- alpha x~ + (1 - alpha) x, z <- clamp(alpha z~ + (1 - alpha) z + y / rho),
+    // y <- y + rho (alpha z~ + (1 - alpha) z_prev - z); every tenth iteration the residual
+    // (|A x - z_prev|_inf + |P x + q + A^T y|_inf) / 4 is compared with `terminate` (:238-247, :381-407).
+    // P x is carried along as M x - diag(M - P) x with M x = alpha rhs + (1 - alpha) M x_prev (exact
+    // recurrence: M x~ = rhs), A x likewise.  Run by wave 0 alone: lane = variable, lane = foot-step.
+    if (engine) {
+      const double mi = P.mu_inv, sig = P.admm_sigma, al = P.admm_alpha, rho = P.admm_rho, rinf = 1e-6;
+      const double big = (double)5e10f;  // BIG_NUMBER through float (SolverMPC.cpp:15, :356)
+      const int max_it = P.admm_max_iter;
+      double r4 = rho;  // rho of the fz <= f_max row of this lane's foot-step (computeConstraintInfos :276-291)
+      if (__builtin_fabs(fmx) < 1e-10) r4 = rho * 1e3;
+      else if (fmx > 1e10) r4 = rinf;
+      const double ir4 = 1.0 / r4, irinf = 1.0 / rinf;
+      double dj[RE], mxv[RE];  // diag(M - P) and M x of this lane's variables
+#pragma unroll
+      for (int q = 0; q < RE; ++q) {
+        const int j = lane + 64 * q;
+        const double f3 = (j < n) ? S.fmaxk[(j / 3) & 63] : 1.0;
+        const double rr = (__builtin_fabs(f3) < 1e-10) ? rho * 1e3 : (f3 > 1e10 ? rinf : rho);
+        dj[q] = sig + ((j % 3 < 2) ? 2.0 * rinf * mi * mi : 4.0 * rinf + rr);
+        mxv[q] = 0.0;
+        xv[q] = 0.0;  // cold start (the unconstrained minimiser computed above is not used)
+      }
+      double z[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0}, ax[5] = {0, 0, 0, 0, 0};
+      auto gather = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
+        double out = 0.0;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          const double cand = __shfl(v[q], j & 63);
+          if ((j >> 6) == q) out = cand;
+        }
+        return out;
+      };
+      // slot quantities (cx, cy, cz) -> this lane's variables: variable j takes component j % 3 of slot j / 3
+      auto scatter3 = [&](double cx, double cy, double cz, double (&out)[RE]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          const int j = lane + 64 * q, sl = (j / 3) & 63, ax3 = j % 3;
+          const double a0 = __shfl(cx, sl), a1 = __shfl(cy, sl), a2 = __shfl(cz, sl);
+          out[q] = (j < n) ? (ax3 == 0 ? a0 : (ax3 == 1 ? a1 : a2)) : 0.0;
+        }
+      };
+      auto Hel = [&](int row, int j) __attribute__((always_inline)) {
+        return Sb.Hp[(j <= row) ? row * (row + 1) / 2 + j : j * (j + 1) / 2 + row];
+      };
+      double resid = __builtin_inf();
+      double* const rv = Sb.D;  // rhs, broadcast through LDS
+      __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);
+      for (int it = 1; it <= max_it; ++it) {
+        // rhs = sigma x - q + A^T (R z - y)                                       (solveLinearSystem :315-323)
+        const double w0 = rinf * z[0] - y[0], w1 = rinf * z[1] - y[1], w2 = rinf * z[2] - y[2],
+                     w3 = rinf * z[3] - y[3], w4 = r4 * z[4] - y[4];
+        double cw[RE], rhs[RE];
+        scatter3(mi * (w0 - w1), mi * (w2 - w3), (w0 + w1) + (w2 + w3) + w4, cw);
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          rhs[q] = sig * xv[q] - gq[q] + cw[q];
+          if (lane + 64 * q < NP) rv[lane + 64 * q] = (lane + 64 * q < n) ? rhs[q] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // x~ = M^-1 rhs
+        double xt[RE];
+#pragma unroll
+        for (int q = 0; q < RE; ++q) xt[q] = 0.0;
+        for (int j0 = 0; j0 < n; j0 += 4) {
+          double rj[4], hv[4][RE];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = (j0 + u < n) ? j0 + u : 0;
+            rj[u] = (j0 + u < n) ? rv[j] : 0.0;
+#pragma unroll
+            for (int q = 0; q < RE; ++q) hv[u][q] = (lane + 64 * q < n) ? Hel(lane + 64 * q, j) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < RE; ++q) xt[q] = __builtin_fma(hv[u][q], rj[u], xt[q]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // z~ = A x~ on the foot-step lanes (f_block rows, SolverMPC.cpp:366-370)
+        const int j3 = 3 * (lane < nst ? lane : 0);
+        const double t0 = gather(xt, j3), t1 = gather(xt, j3 + 1), t2 = gather(xt, j3 + 2);
+        const double zt[5] = {mi * t0 + t2, -mi * t0 + t2, mi * t1 + t2, -mi * t1 + t2, t2};
+        // x, M x (stepX :340-347)
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          xv[q] = al * xt[q] + (1.0 - al) * xv[q];
+          mxv[q] = al * rhs[q] + (1.0 - al) * mxv[q];
+        }
+        // z, y, A x (stepZ :349-358, stepY :360-367)
+        double pmax = 0.0;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const double rr = (r < 4) ? rinf : r4, ir = (r < 4) ? irinf : ir4, ub = (r < 4) ? big : fmx;
+          const double zr = al * zt[r] + (1.0 - al) * z[r];
+          double zn = zr + ir * y[r];
+          zn = zn < 0.0 ? 0.0 : zn;
+          zn = zn > ub ? ub : zn;
+          y[r] = y[r] + rr * (zr - zn);
+          ax[r] = al * zt[r] + (1.0 - al) * ax[r];  // A x of the relaxed iterate
+          const double pr = __builtin_fabs(ax[r] - z[r]);  // ... against the PREVIOUS z (:388)
+          pmax = pr > pmax ? pr : pmax;
+          z[r] = zn;
+        }
+        iters = it;
+        if (it % 10 == 0) {  // residual check (:238-247)
+          double ey[RE];
+          scatter3(mi * (y[0] - y[1]), mi * (y[2] - y[3]), (y[0] + y[1]) + (y[2] + y[3]) + y[4], ey);
+          double dmax = 0.0;
+#pragma unroll
+          for (int q = 0; q < RE; ++q) {
+            const double dv = __builtin_fabs((mxv[q] - dj[q] * xv[q]) + gq[q] + ey[q]);
+            if (lane + 64 * q < n) dmax = dv > dmax ? dv : dmax;
+          }
+          if (!(lane < nst)) pmax = 0.0;
+          // max over the wave of non-negative doubles: bit pattern order == value order
+          const double pm = wave_max_pos_f64(pmax), dm = wave_max_pos_f64(dmax);
+          resid = (dm + pm) * 0.25;
+          if (resid < P.admm_term || it >= max_it) break;
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      QMPC_TICK(6);
+      // outputs: q_soln = the ADMM iterate (SolverMPC.cpp:598-602 / :613-617), not an exact minimiser
+      if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+      bool nf = false;
+#pragma unroll
+      for (int q = 0; q < RE; ++q) {
+        const int j = lane + 64 * q;
+        if (j < n) {
+          const int k = S.sidx[j / 3], ax3 = j % 3;
+          if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax3] = (float)xv[q];
+          if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax3] = xv[q];
+          nf |= !(__builtin_fabs(xv[q]) < __builtin_inf());
+        }
+      }
+      int status = (resid < P.admm_term) ? 0 : QMPC_DEV_ST_MAXITER;
+      if (__ballot(nf)) status |= QMPC_DEV_ST_NONFINITE;
+      if (lane == 0) {
+        P.status[rid] = S.status | status;
+        if (P.iters) P.iters[rid] = iters;
+        S.mode = 0;
+      }
+    }
+  } else if constexpr (V5) {
     if (engine) {
       constexpr int NPE = NP, KS = C::KS, EV = NPE + KS, KEV = (C::NPOOL / EV) & ~3;
       // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
@@ -1900,6 +2082,21 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
   }
 }
 
+// JCQP alternate (update_solver_settings' use_jcqp = 1 / 2): same assembly and sweep, ADMM instead of the
+// active set; record mode only, same size-class chain
+template <int RB>
+__global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_admm_kernel(const QmpcParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
+  Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  int rid = (int)blockIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 3 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+  if (P.list) {
+    if ((int)blockIdx.x >= *P.count) return;  // uniform
+    rid = P.list[blockIdx.x];
+  }
+  solve_one<RB, false, false, true>(rid, (int)threadIdx.x, S, P);
+}
+
 extern "C" size_t qmpc_smem_bytes(int rb) {
   switch (rb) {
     case 1: return sizeof(Smem<1>);
@@ -1917,8 +2114,15 @@ hipError_t prepare_one() {
                              (int)sizeof(Smem<RB>));
 }
 template <int RB>
+hipError_t prepare_admm() {
+  return hipFuncSetAttribute((const void*)qmpc_admm_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)sizeof(Smem<RB>));
+}
+template <int RB>
 void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
-  if (cmd)
+  if (P->admm_mode)
+    hipLaunchKernelGGL((qmpc_admm_kernel<RB>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
+  else if (cmd)
     hipLaunchKernelGGL((qmpc_solve_kernel<RB, true>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
   else
     hipLaunchKernelGGL((qmpc_solve_kernel<RB, false>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
@@ -1934,7 +2138,11 @@ extern "C" hipError_t qmpc_prepare(void) {
   if ((e = prepare_one<4, true>()) != hipSuccess) return e;
   if ((e = prepare_one<1, true>()) != hipSuccess) return e;
   if ((e = prepare_one<2, true>()) != hipSuccess) return e;
-  return prepare_one<3, true>();
+  if ((e = prepare_one<3, true>()) != hipSuccess) return e;
+  if ((e = prepare_admm<1>()) != hipSuccess) return e;
+  if ((e = prepare_admm<4>()) != hipSuccess) return e;
+  if ((e = prepare_admm<2>()) != hipSuccess) return e;
+  return prepare_admm<3>();
 }
 
 // the command-mode instantiation is selected by P->c_position != nullptr

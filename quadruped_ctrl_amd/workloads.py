@@ -258,8 +258,10 @@ class Rollout:
 
     HIP = np.array([[.19, -.111], [.19, .111], [-.19, -.111], [-.19, .111]])
 
-    def __init__(self, batch, horizon=10, gait="trot", seed=0, v_des=0.5):
+    def __init__(self, batch, horizon=10, gait="trot", seed=0, v_des=0.5, kick=1.0):
         rng = np.random.default_rng(SEED0 + 5000 + seed)
+        self.rng = rng
+        self.kick = kick       # per-cycle disturbance scale (pushes), so that constraints keep binding
         self.B, self.h = batch, horizon
         h = horizon
         table = {"trot": ((0, h // 2, h // 2, 0), (h // 2,) * 4),
@@ -277,6 +279,7 @@ class Rollout:
         self.w = rng.normal(0, 0.1, (batch, 3))
         self.vdes = np.zeros((batch, 2))
         self.vdes[:, 0] = 0.0 if gait == "stand" else v_des
+        self.v_cmd = v_des
         self.yaw_rate = rng.normal(0, 0.2, batch) * (0.0 if gait == "stand" else 1.0)
         self.feet = np.zeros((batch, 4, 3))
         self._place(np.ones((batch, 4), bool))
@@ -316,6 +319,13 @@ class Rollout:
                  r=r.astype(f32), yaw=self.rpy[:, 2].astype(f32), traj=traj.reshape(B, 12 * h).astype(f32))
         return _finish(d, B, h, self.contact_table())
 
+    def demand(self, vx, vy=0.0, yaw_rate=None):
+        """Sustained command change (the robot has to accelerate / turn for many cycles: friction
+        limits bind persistently instead of by chance)."""
+        self.vdes[:, 0], self.vdes[:, 1] = vx, vy
+        if yaw_rate is not None:
+            self.yaw_rate[:] = yaw_rate
+
     def advance(self, grf):
         """Integrate one MPC step with the first-step forces grf[B,12] (world frame, foot-major)."""
         f = np.asarray(grf, np.float64).reshape(self.B, 4, 3)
@@ -330,6 +340,9 @@ class Rollout:
         self.v = self.v + acc * DT_MPC
         self.rpy = self.rpy + np.einsum("bji,bj->bi", R, self.w) * DT_MPC
         self.w = self.w + np.einsum("bij,bj->bi", Iinv, tau) * DT_MPC
+        if self.kick:          # pushes: the spread of SURVEY 8d's synthetic states, re-injected every cycle
+            self.v += self.rng.normal(0, 0.06 * self.kick, (self.B, 3))
+            self.w += self.rng.normal(0, 0.15 * self.kick, (self.B, 3))
         before = self.contact_table()[:, :4] != 0
         self.it = (self.it + 1) % self.h
         after = self.contact_table()[:, :4] != 0

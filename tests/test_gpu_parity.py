@@ -334,6 +334,10 @@ def test_full_size_kkt_properties(cfg, B, mpc_factory):
 
 
 def _shim():
+    # (torch first: it ships its own HIP runtime, and whichever copy of libamdhip64 is loaded first
+    #  serves the whole process -- a C++ user of the shim never loads torch and is not affected)
+    import torch
+    assert torch.cuda.is_available()
     path = os.path.join(ROOT, "quadruped_ctrl_amd", "libconvexmpc_shim.so")
     lib = C.CDLL(path)
     lib.get_solution.restype = C.c_double
@@ -412,19 +416,77 @@ def test_reference_shim_real_horizons_double_entry_drag_and_horizon_changes():
                 assert lib.get_solution(12 * h) == 0.0                    # past the horizon: 0, no overrun
 
 
-def test_reference_shim_reports_use_jcqp():
-    """update_solver_settings(..., use_jcqp != 0) is recorded and REPORTED (bit 256 of
-    qmpc_shim_last_status), not swallowed; the answer is still the exact minimiser."""
+def test_jcqp_alternate_vs_model(mpc_factory):
+    """use_jcqp = 1 / 2 reproduces the reference's JCQP ADMM (QpProblem.cpp:178-269) --
+    same iterate after the same number of iterations as the numpy restatement (oracle/jcqp_model.py), for
+    the caller's settings (terminate 0.1 -> ~1e-3 from the minimiser) and for tight settings (-> the
+    minimiser itself), on every size class."""
+    from oracle import jcqp_model as J
+    cases = [(W.make_config(2, batch=12), {}),                                        # class 1
+             (W.make_config(4, batch=12), dict(rho=1e-2, sigma=1e-6, terminate=1e-7, max_iter=6000)),
+             (W.make_config(3, batch=4), {}),                                         # class 4 (n_r = 96)
+             (W.make_standing(3, 10), dict(rho=1e-3, sigma=1e-7, terminate=1e-3, max_iter=3000)),   # class 2
+             (W.make_standing(2, 14), {})]                                            # class 3
+    for b, kw in cases:
+        B, h = b["batch"], b["horizon"]
+        exact = mpc_factory(b).solve(b, full=True)["soln"]
+        for mode in (2, 1):
+            m = mpc_factory(b)
+            m.settings_jcqp(mode, **kw)
+            Hd, gd, ld = m.debug_dump(B)
+            res = m.solve(b, full=True)
+            m.debug_off()
+            Hd, gd = Hd.cpu().numpy(), gd.cpu().numpy()
+            rho, sigma = kw.get("rho", 1e-7), kw.get("sigma", 1e-8)
+            mi = float(np.float32(1) / np.float32(b["mu"]))
+            for i in range(B):
+                # (a) end to end against the reference-style pipeline (float-assembled QP): the iteration count
+                # and the iterate up to the float-assembly noise, which rho = 1e-7 amplifies by cond(P) ~ 1e3
+                x, it, resid = J.solve(b, i, mode, **kw)
+                assert abs(int(res["iters"][i]) - it) <= 10, (mode, i, res["iters"][i], it)
+                scale = max(np.abs(x).max(), 1.0)
+                assert np.abs(res["soln"][i] - x).max() / scale < 5e-4
+                # (b) the ADMM arithmetic itself: the numpy restatement fed the GPU's OWN P, q (the dump holds
+                # M = P + sigma I + A^T R A, whose extra diagonal is known in closed form) -> same iterate
+                P_, q_, A_, l_, u_, vi = J.mpc_problem(b, i, mode)
+                n = q_.size
+                R = J.constraint_rho(l_, u_, rho)
+                extra = sigma + (A_ * A_ * R[:, None]).sum(0)
+                Pg = Hd[i][:n, :n] - np.diag(extra)
+                xg, itg, rg = J.run_from_dense(Pg, gd[i][:n], A_, l_, u_, kw.get("max_iter", 10000), rho, sigma,
+                                               kw.get("alpha", 1.5), kw.get("terminate", 0.1))
+                assert res["iters"][i] == itg, (mode, i, res["iters"][i], itg)
+                assert np.abs(res["soln"][i][vi] - xg).max() / max(np.abs(xg).max(), 1.0) < 1e-8
+                assert (res["status"][i] & 47) == (0 if rg < kw.get("terminate", 0.1) else 1)
+            d = np.abs(res["soln"] - exact).max() / np.abs(exact).max()
+            if kw.get("terminate", 0.1) <= 1e-6:
+                assert d < 1e-5                     # tight settings: the ADMM reaches the exact minimiser
+            else:
+                assert 1e-6 < d < 5e-2              # the caller's settings: an approximation, as in the reference
+            if mode == 1:                           # full problem: swing forces are ~0 but not exactly 0
+                sw = np.repeat(b["gait"] == 0, 3, axis=1)
+                assert np.abs(res["soln"][sw]).max() < 1.0 if sw.any() else True
+            m.settings_jcqp(0)
+            assert np.array_equal(m.solve(b, full=True)["soln"], exact)      # back to the exact solve
+
+
+def test_reference_shim_use_jcqp():
+    """update_solver_settings(..., use_jcqp): 0 = exact solve; 1 / 2 = the reference's ADMM alternate with the
+    knobs of that very call (convexMPC_interface.cpp:107-119); any other value is reported (bit 256)."""
+    from oracle import jcqp_model as J
     lib = _shim()
     b = W.make_config(1, batch=1)
     base = _shim_solve(lib, b, 0)
     assert lib.qmpc_shim_last_status() == 0
     for flag in (1.0, 2.0):
         sol = _shim_solve(lib, b, 0, use_jcqp=flag)
-        assert lib.qmpc_shim_last_status() == 256
-        assert np.array_equal(sol, base)
-    _shim_solve(lib, b, 0)
-    assert lib.qmpc_shim_last_status() == 0
+        x, it, resid = J.solve(b, 0, int(flag))
+        assert lib.qmpc_shim_last_status() == 0 and lib.qmpc_shim_last_iters() == it
+        assert np.abs(sol - x).max() / np.abs(x).max() < 2e-5
+        assert 1e-6 < np.abs(sol - base).max() / np.abs(base).max() < 5e-2
+    sol = _shim_solve(lib, b, 0, use_jcqp=3.0)
+    assert lib.qmpc_shim_last_status() == 256 and np.array_equal(sol, base)
+    assert np.array_equal(_shim_solve(lib, b, 0), base) and lib.qmpc_shim_last_status() == 0
 
 
 def test_one_handle_two_streams_is_ordered(mpc_factory):

@@ -22,8 +22,10 @@ from quadruped_ctrl_amd import workloads as W  # noqa: E402
 from quadruped_ctrl_amd.binding import BatchedConvexMPC  # noqa: E402
 
 
-def run(gait, horizon, B, cycles, seed=0):
-    ro = W.Rollout(B, horizon, gait, seed=seed)
+def run(gait, horizon, B, cycles, seed=0, kick=1.0, demand=None, label=None):
+    ro = W.Rollout(B, horizon, gait, seed=seed, kick=kick)
+    if demand:
+        ro.demand(*demand)
     b = ro.record()
     cold = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
     warm = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
@@ -38,6 +40,7 @@ def run(gait, horizon, B, cycles, seed=0):
         d = cold.upload(b)
         ic, outc = cold.make_args(d, oc)
         iw, outw = warm.make_args(d, ow)
+        cold.solve_async(B, ic, outc)          # untimed: same clocks / caches for both timed solves
         torch.cuda.synchronize()
         e[0].record(); cold.solve_async(B, ic, outc); e[1].record()
         e[2].record(); warm.solve_async(B, iw, outw); e[3].record()
@@ -54,7 +57,7 @@ def run(gait, horizon, B, cycles, seed=0):
     cold.close(); warm.close()
     steady = rows[3:]                      # the first cycles have nothing to warm-start from
     agg = lambda k: float(np.mean([r[k] for r in steady]))
-    return {"gait": gait, "horizon": horizon, "batch": B, "cycles": cycles,
+    return {"scenario": label or f"{gait}, random pushes x{kick}", "gait": gait, "horizon": horizon, "batch": B, "cycles": cycles,
             "cold_iters_mean": agg("cold_iters"), "warm_iters_mean": agg("warm_iters"),
             "cold_iters_max": max(r["cold_max"] for r in steady), "warm_iters_max": max(r["warm_max"] for r in steady),
             "cold_ms_mean": agg("cold_ms"), "warm_ms_mean": agg("warm_ms"),
@@ -68,9 +71,14 @@ def main():
     ap.add_argument("--cycles", type=int, default=40)
     a = ap.parse_args()
     out = [run("trot", 10, a.batch, a.cycles), run("mixed", 10, a.batch, a.cycles), run("stand", 10, a.batch, a.cycles),
-           run("trot", 16, a.batch, a.cycles), run("stand", 14, min(a.batch, 512), a.cycles)]
+           run("trot", 16, a.batch, a.cycles), run("stand", 14, min(a.batch, 512), a.cycles),
+           # sustained demands: accelerate from 0.5 to 1.6 m/s with a lateral command and a turn, light pushes
+           run("trot", 10, a.batch, a.cycles, kick=0.25, demand=(1.6, 0.4, 1.0), label="trot, accelerate + turn, light pushes"),
+           run("mixed", 10, a.batch, a.cycles, kick=0.25, demand=(1.6, 0.4, 1.0), label="mixed gaits, accelerate + turn, light pushes"),
+           run("stand", 10, a.batch, a.cycles, kick=0.25, demand=(0.0, 0.0, 0.0), label="stand, braking from 0.5 m/s, light pushes"),
+           run("trot", 10, a.batch, a.cycles, kick=0.0, demand=(1.6, 0.4, 1.0), label="trot, accelerate + turn, no pushes")]
     for r in out:
-        print(f"# {r['gait']:6s} h={r['horizon']:2d}: iters {r['cold_iters_mean']:.2f} -> {r['warm_iters_mean']:.2f} "
+        print(f"# {r['scenario']:50s} h={r['horizon']:2d}: iters {r['cold_iters_mean']:.2f} -> {r['warm_iters_mean']:.2f} "
               f"(max {r['cold_iters_max']} -> {r['warm_iters_max']}), ms/cycle {r['cold_ms_mean']:.4f} -> {r['warm_ms_mean']:.4f}, "
               f"max rel diff {r['max_rel_diff']:.1e}, failed {r['failed']}, fallbacks {r['warm_fallbacks']}", file=sys.stderr)
     print(json.dumps({"warm_rollout": out}, indent=1))
