@@ -161,7 +161,8 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
  * continues with the normal dual active-set iteration; (b) writes the final working set back.
  * The result is the same unique minimiser as a cold solve (the QP is strictly convex); only the
  * iteration path is shorter.  Row order must follow the robots (row b belongs to robot b of every
- * call).  NULL switches warm starting off.  The largest size class (n_r > 128) always starts cold. */
+ * call).  NULL switches warm starting off.  The largest size class (n_r > 128) always starts cold, and so
+ * does qmpc_solve_commands (warm starting is wired into the record entry points). */
 #define QMPC_WS_SLOTS 64
 int qmpc_set_warm_start(qmpc_handle h, int32_t* ws_dev, int shift_steps);
 
@@ -329,6 +330,27 @@ int qmpc_leg_torques(qmpc_handle h, int batch, const qmpc_leg_command* cmd, floa
 int qmpc_swing_trajectory(qmpc_handle h, int n_feet, const float* p0, const float* pf,
                           const float* height, const float* phase, const float* swing_time,
                           float* p, float* v, float* a, void* stream);
+
+/* LinearKFPositionVelocityEstimator (src/Controllers/PositionVelocityEstimator.cpp:18-221): the
+ * 18-state (body position, velocity, four foot positions) / 28-measurement Kalman filter of the state
+ * estimator, one step per call for every robot.  The filter state lives in caller-owned DEVICE arrays. */
+typedef struct {
+  float* xhat;                /* [B][18]  _xhat, in/out */
+  float* P;                   /* [B][324] _P (18x18 row-major), in/out */
+  const float* r_body;        /* [B][9]   result->rBody */
+  const float* a_world;       /* [B][3]   result->aWorld */
+  const float* omega_body;    /* [B][3]   result->omegaBody */
+  const float* contact_phase; /* [B][4]   result->contactEstimate */
+  const float* leg_p;         /* [B][12]  legControllerData[leg].p (qmpc_leg_kinematics) */
+  const float* leg_v;         /* [B][12]  legControllerData[leg].v */
+  float* position;            /* [B][3]   out: result->position */
+  float* v_world;             /* [B][3]   out: result->vWorld */
+  float* v_body;              /* [B][3]   out: result->vBody (may be NULL) */
+} qmpc_kf_state;
+/* setup() (:18-63): xhat = 0, P = 100 I. */
+int qmpc_kf_init(qmpc_handle h, int batch, float* xhat, float* P, void* stream);
+/* run() (:66-221).  Hip locations are the Mini Cheetah's (MiniCheetah.h:25-26,105): (+-0.19, +-0.049, 0). */
+int qmpc_kf_step(qmpc_handle h, int batch, const qmpc_kf_state* st, void* stream);
 
 /* Last HIP error string for this handle ("" if none). */
 const char* qmpc_last_error(qmpc_handle h);

@@ -65,3 +65,21 @@ def swing(p0, pf, height, phase, swing_time):
     p, v, a = (np.zeros((n, 3), np.float32) for _ in range(3))
     lib().oracle_swing_batch(C.c_int(n), _p(p0), _p(pf), _p(height), _p(phase), _p(swing_time), _p(p), _p(v), _p(a))
     return p, v, a
+
+
+HIP = np.array([0.19, 0.049, 0.0], np.float32)   # _abadLocation, Dynamics/MiniCheetah.h:25-26,105
+
+
+def kf_init(batch):
+    """LinearKFPositionVelocityEstimator::setup: xhat = 0, P = 100 I."""
+    return np.zeros((batch, 18), np.float32), np.tile((100 * np.eye(18, dtype=np.float32)).reshape(1, 324), (batch, 1))
+
+
+def kf_step(xhat, P, r_body, a_world, omega_body, contact, leg_p, leg_v):
+    """One run() for every robot; xhat, P updated IN PLACE (float32 contiguous).  -> position, v_world, v_body."""
+    B = xhat.shape[0]
+    assert xhat.dtype == np.float32 and P.dtype == np.float32 and xhat.flags.c_contiguous and P.flags.c_contiguous
+    a = [_f(x) for x in (r_body, a_world, omega_body, contact, leg_p, leg_v)]
+    pos, vw, vb = (np.zeros((B, 3), np.float32) for _ in range(3))
+    lib().oracle_kf_step_batch(_p(HIP), C.c_int(B), _p(xhat), _p(P), *[_p(x) for x in a], _p(pos), _p(vw), _p(vb))
+    return pos, vw, vb

@@ -149,3 +149,182 @@ void oracle_swing_batch(int n, const float* p0, const float* pf, const float* he
                         const float* swingTime, float* p, float* v, float* a) {
   for (int t = 0; t < n; t++) oracle_swing(p0 + 3 * t, pf + 3 * t, height[t], phase[t], swingTime[t], p + 3 * t, v + 3 * t, a + 3 * t);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * LinearKFPositionVelocityEstimator<float> (Controllers/PositionVelocityEstimator.cpp:18-221): one
+ * run() of the 18-state / 28-measurement Kalman filter (body position, velocity, four foot positions;
+ * measurements: foot positions and velocities relative to the body from the leg kinematics, and the
+ * foot heights), float arithmetic, dense like the reference.  setup() (:18-63): xhat = 0, P = 100 I,
+ * dt = 0.002.  The two S.lu().solve(...) calls (:183, :186) are restated as ONE unblocked LU with
+ * partial pivoting applied to both right-hand sides (Eigen's PartialPivLU is blocked, so its rounding
+ * differs in the last bits; parity with Eigen is unpinned -- Eigen is absent -- like every other
+ * Eigen-backed piece).
+ */
+#define KF_N 18
+#define KF_M 28
+
+static float kf_q_process(int k, float dt) { /* run() :73-76 with _Q0 of setup() :56-60 */
+  const float process_noise_pimu = 0.02f, process_noise_vimu = 0.02f, process_noise_pfoot = 0.002f;
+  if (k < 3) return (dt / 20.f) * process_noise_pimu;
+  if (k < 6) return (dt * 9.8f / 20.f) * process_noise_vimu;
+  return dt * process_noise_pfoot;
+}
+
+/* hip = {abadLocation x, y, z} (Dynamics/MiniCheetah.h:25-26,105: 0.19, 0.049, 0) */
+void oracle_kf_step(const float hip[3], float xhat[KF_N], float P[KF_N * KF_N], const float rBody[9],
+                    const float aWorld[3], const float omegaBody[3], const float contact[4], const float legp[12],
+                    const float legv[12], float position[3], float vWorld[3], float vBody[3]) {
+  const float dt = 0.002f;
+  const float sensor_noise_pimu_rel_foot = 0.001f, sensor_noise_vimu_rel_foot = 0.1f, sensor_noise_zfoot = 0.001f;
+  float Q[KF_N], R[KF_M]; /* both stay diagonal */
+  for (int k = 0; k < KF_N; k++) Q[k] = kf_q_process(k, dt);
+  for (int k = 0; k < KF_M; k++)
+    R[k] = 1.f * (k < 12 ? sensor_noise_pimu_rel_foot : (k < 24 ? sensor_noise_vimu_rel_foot : sensor_noise_zfoot));
+  const float a[3] = {aWorld[0] + 0.f, aWorld[1] + 0.f, aWorld[2] + -9.81f}; /* :95 */
+  float y[KF_M];
+  const float p0[3] = {xhat[0], xhat[1], xhat[2]}, v0[3] = {xhat[3], xhat[4], xhat[5]};
+  for (int i = 0; i < 4; i++) { /* :118-166 */
+    const float ph[3] = {(i == 0 || i == 1) ? hip[0] : -hip[0], (i == 1 || i == 3) ? hip[1] : -hip[1], hip[2]};
+    float p_rel[3], dp_rel[3], w[3], p_f[3], dp_f[3];
+    for (int k = 0; k < 3; k++) {
+      p_rel[k] = ph[k] + legp[3 * i + k];
+      dp_rel[k] = legv[3 * i + k];
+    }
+    /* omegaBody.cross(p_rel) + dp_rel */
+    w[0] = (omegaBody[1] * p_rel[2] - omegaBody[2] * p_rel[1]) + dp_rel[0];
+    w[1] = (omegaBody[2] * p_rel[0] - omegaBody[0] * p_rel[2]) + dp_rel[1];
+    w[2] = (omegaBody[0] * p_rel[1] - omegaBody[1] * p_rel[0]) + dp_rel[2];
+    for (int k = 0; k < 3; k++) { /* Rbod = rBody^T */
+      p_f[k] = (rBody[0 * 3 + k] * p_rel[0] + rBody[1 * 3 + k] * p_rel[1]) + rBody[2 * 3 + k] * p_rel[2];
+      dp_f[k] = (rBody[0 * 3 + k] * w[0] + rBody[1 * 3 + k] * w[1]) + rBody[2 * 3 + k] * w[2];
+    }
+    float trust = 1.f;
+    const float phase = fminf(contact[i], 1.f);
+    const float trust_window = 0.2f;
+    if (phase < trust_window) trust = phase / trust_window;
+    else if (phase > (1.f - trust_window)) trust = (1.f - phase) / trust_window;
+    const float high_suspect_number = 100.f;
+    const float factor = 1.f + (1.f - trust) * high_suspect_number;
+    for (int k = 0; k < 3; k++) {
+      Q[6 + 3 * i + k] = factor * Q[6 + 3 * i + k];
+      R[3 * i + k] = 1 * R[3 * i + k];
+      R[12 + 3 * i + k] = factor * R[12 + 3 * i + k];
+      y[3 * i + k] = -p_f[k];                                        /* _ps */
+      y[12 + 3 * i + k] = (1.0f - trust) * v0[k] + trust * (-dp_f[k]); /* _vs */
+    }
+    R[24 + i] = factor * R[24 + i];
+    y[24 + i] = (1.0f - trust) * (p0[2] + p_f[2]); /* pzs */
+  }
+  /* _xhat = _A * _xhat + _B * a  (:170) */
+  for (int k = 0; k < 3; k++) {
+    xhat[k] = xhat[k] + dt * xhat[3 + k];
+    xhat[3 + k] = xhat[3 + k] + dt * a[k];
+  }
+  /* Pm = A P A^T + Q (:172): A = [[I, dt I, 0], [0, I, 0], [0, 0, I]] */
+  static float AP[KF_N * KF_N], Pm[KF_N * KF_N], CP[KF_M * KF_N], K1[KF_N * KF_M], Saug[KF_M * (KF_M + 1 + KF_N)];
+  static float T1[KF_N * KF_N];
+  for (int i = 0; i < KF_N; i++)
+    for (int j = 0; j < KF_N; j++) AP[i * KF_N + j] = (i < 3) ? P[i * KF_N + j] + dt * P[(i + 3) * KF_N + j] : P[i * KF_N + j];
+  for (int i = 0; i < KF_N; i++)
+    for (int j = 0; j < KF_N; j++) {
+      float v = (j < 3) ? AP[i * KF_N + j] + dt * AP[i * KF_N + j + 3] : AP[i * KF_N + j];
+      if (i == j) v = v + Q[i];
+      Pm[i * KF_N + j] = v;
+    }
+  /* C row r: position rows r = 3i+k: e_k - e_{6+3i+k}; velocity rows 12+3i+k: e_{3+k}; height rows 24+i: e_{8+3i} */
+#define CROW_A(r) ((r) < 12 ? (r) % 3 : ((r) < 24 ? 3 + (r) % 3 : 8 + 3 * ((r) - 24)))
+#define CROW_B(r) ((r) < 12 ? 6 + (r) : -1)
+  float ey[KF_M];
+  for (int r = 0; r < KF_M; r++) { /* yModel = C xhat; ey = y - yModel (:175-176) */
+    const float ym = (CROW_B(r) >= 0) ? xhat[CROW_A(r)] - xhat[CROW_B(r)] : xhat[CROW_A(r)];
+    ey[r] = y[r] - ym;
+  }
+  for (int r = 0; r < KF_M; r++) /* C Pm */
+    for (int j = 0; j < KF_N; j++)
+      CP[r * KF_N + j] = (CROW_B(r) >= 0) ? Pm[CROW_A(r) * KF_N + j] - Pm[CROW_B(r) * KF_N + j] : Pm[CROW_A(r) * KF_N + j];
+  const int W = KF_M + 1 + KF_N; /* [ S | ey | C ] */
+  for (int r = 0; r < KF_M; r++) {
+    for (int c = 0; c < KF_M; c++) { /* S = C Pm C^T + R (:177) */
+      float v = (CROW_B(c) >= 0) ? CP[r * KF_N + CROW_A(c)] - CP[r * KF_N + CROW_B(c)] : CP[r * KF_N + CROW_A(c)];
+      if (r == c) v = v + R[r];
+      Saug[r * W + c] = v;
+    }
+    Saug[r * W + KF_M] = ey[r];
+    for (int j = 0; j < KF_N; j++) Saug[r * W + KF_M + 1 + j] = (j == CROW_A(r)) ? 1.f : ((j == CROW_B(r)) ? -1.f : 0.f);
+  }
+  for (int i = 0; i < KF_N; i++) /* Pm C^T */
+    for (int c = 0; c < KF_M; c++)
+      K1[i * KF_M + c] = (CROW_B(c) >= 0) ? Pm[i * KF_N + CROW_A(c)] - Pm[i * KF_N + CROW_B(c)] : Pm[i * KF_N + CROW_A(c)];
+  /* LU with partial pivoting on the augmented matrix, then back substitution (:183, :186) */
+  for (int k = 0; k < KF_M; k++) {
+    int piv = k;
+    float best = fabsf(Saug[k * W + k]);
+    for (int r = k + 1; r < KF_M; r++)
+      if (fabsf(Saug[r * W + k]) > best) {
+        best = fabsf(Saug[r * W + k]);
+        piv = r;
+      }
+    if (piv != k)
+      for (int c = 0; c < W; c++) {
+        const float t = Saug[k * W + c];
+        Saug[k * W + c] = Saug[piv * W + c];
+        Saug[piv * W + c] = t;
+      }
+    for (int r = k + 1; r < KF_M; r++) {
+      const float l = Saug[r * W + k] / Saug[k * W + k];
+      for (int c = k + 1; c < W; c++) Saug[r * W + c] = Saug[r * W + c] - l * Saug[k * W + c];
+    }
+  }
+  for (int c = KF_M; c < W; c++) /* back substitution, every right-hand side */
+    for (int r = KF_M - 1; r >= 0; r--) {
+      float acc = Saug[r * W + c];
+      for (int j = r + 1; j < KF_M; j++) acc = acc - Saug[r * W + j] * Saug[j * W + c];
+      Saug[r * W + c] = acc / Saug[r * W + r];
+    }
+  /* _xhat += Pm C^T S_ey (:184) */
+  for (int i = 0; i < KF_N; i++) {
+    float acc = 0.f;
+    for (int c = 0; c < KF_M; c++) acc = acc + K1[i * KF_M + c] * Saug[c * W + KF_M];
+    xhat[i] = xhat[i] + acc;
+  }
+  /* _P = (I - Pm C^T S_C) Pm (:187), symmetrised (:189-190) */
+  for (int i = 0; i < KF_N; i++)
+    for (int j = 0; j < KF_N; j++) {
+      float acc = 0.f;
+      for (int c = 0; c < KF_M; c++) acc = acc + K1[i * KF_M + c] * Saug[c * W + KF_M + 1 + j];
+      T1[i * KF_N + j] = ((i == j) ? 1.f : 0.f) - acc;
+    }
+  for (int i = 0; i < KF_N; i++)
+    for (int j = 0; j < KF_N; j++) {
+      float acc = 0.f;
+      for (int k = 0; k < KF_N; k++) acc = acc + T1[i * KF_N + k] * Pm[k * KF_N + j];
+      AP[i * KF_N + j] = acc;
+    }
+  for (int i = 0; i < KF_N; i++)
+    for (int j = 0; j < KF_N; j++) P[i * KF_N + j] = (AP[i * KF_N + j] + AP[j * KF_N + i]) / 2.f;
+  if (P[0] * P[KF_N + 1] - P[1] * P[KF_N] > 0.000001f) { /* :192-196 */
+    for (int i = 0; i < 2; i++)
+      for (int j = 2; j < KF_N; j++) {
+        P[i * KF_N + j] = 0.f;
+        P[j * KF_N + i] = 0.f;
+      }
+    P[0] = P[0] / 10.f;
+    P[1] = P[1] / 10.f;
+    P[KF_N] = P[KF_N] / 10.f;
+    P[KF_N + 1] = P[KF_N + 1] / 10.f;
+  }
+  for (int k = 0; k < 3; k++) {
+    position[k] = xhat[k];
+    vWorld[k] = xhat[3 + k];
+  }
+  for (int k = 0; k < 3; k++) /* vBody = rBody * vWorld (:212-214) */
+    vBody[k] = (rBody[3 * k] * xhat[3] + rBody[3 * k + 1] * xhat[4]) + rBody[3 * k + 2] * xhat[5];
+}
+
+void oracle_kf_step_batch(const float hip[3], int batch, float* xhat, float* P, const float* rBody, const float* aWorld,
+                          const float* omegaBody, const float* contact, const float* legp, const float* legv,
+                          float* position, float* vWorld, float* vBody) {
+  for (int b = 0; b < batch; b++)
+    oracle_kf_step(hip, xhat + 18 * b, P + 324 * b, rBody + 9 * b, aWorld + 3 * b, omegaBody + 3 * b, contact + 4 * b,
+                   legp + 12 * b, legv + 12 * b, position + 3 * b, vWorld + 3 * b, vBody + 3 * b);
+}

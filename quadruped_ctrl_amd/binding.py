@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 9              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 10              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_NONFINITE = 32
 ST_ERROR_MASK = 15 | 32
@@ -23,7 +23,9 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
-           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp"]
+           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step"]
+
+KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
 # qmpc_leg_command fields (include/qmpc.h), in declaration order
 LEG_F32 = ("tau_ff", "force_ff", "kp_cart", "kd_cart", "p_des", "v_des", "q", "qd", "J", "p", "v")
@@ -58,6 +60,11 @@ class Record(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in REC_FIELDS]
 
 
+class KfState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v",
+                                          "position", "v_world", "v_body")]
+
+
 class LegCommand(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in LEG_F32] + [("kp_joint", C.c_float), ("kd_joint", C.c_float)]
 
@@ -90,6 +97,8 @@ def load_library():
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.qmpc_kf_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.qmpc_kf_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(KfState), C.c_void_p]
         lib.qmpc_settings_jcqp.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 4
         lib.qmpc_set_leg_geometry.argtypes = [C.c_void_p] + [C.c_double] * 4
         lib.qmpc_leg_kinematics.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
@@ -359,6 +368,25 @@ class BatchedConvexMPC:
         self._check(self.lib.qmpc_leg_torques(self.h, B, C.byref(lc), tau.data_ptr(), qdes.data_ptr(),
                                               self._stream_ptr(stream)), "qmpc_leg_torques")
         return tau, qdes
+
+    def kf_init(self, batch, stream=None):
+        """LinearKFPositionVelocityEstimator::setup -> (xhat [B,18], P [B,324]) device tensors."""
+        t = self.torch
+        xhat = t.empty((batch, 18), dtype=t.float32, device=self.device)
+        P = t.empty((batch, 324), dtype=t.float32, device=self.device)
+        self._check(self.lib.qmpc_kf_init(self.h, batch, xhat.data_ptr(), P.data_ptr(), self._stream_ptr(stream)), "qmpc_kf_init")
+        return xhat, P
+
+    def kf_step(self, xhat, P, r_body, a_world, omega_body, contact_phase, leg_p, leg_v, stream=None):
+        """LinearKFPositionVelocityEstimator::run on device tensors; xhat, P are updated in place.
+        Returns (position, v_world, v_body) [B,3]."""
+        t = self.torch
+        B = xhat.shape[0]
+        pos, vw, vb = (t.empty((B, 3), dtype=t.float32, device=self.device) for _ in range(3))
+        st = KfState(xhat.data_ptr(), P.data_ptr(), r_body.data_ptr(), a_world.data_ptr(), omega_body.data_ptr(),
+                     contact_phase.data_ptr(), leg_p.data_ptr(), leg_v.data_ptr(), pos.data_ptr(), vw.data_ptr(), vb.data_ptr())
+        self._check(self.lib.qmpc_kf_step(self.h, B, C.byref(st), self._stream_ptr(stream)), "qmpc_kf_step")
+        return pos, vw, vb
 
     def swing_trajectory(self, p0, pf, height, phase, swing_time, stream=None):
         """computeSwingTrajectoryBezier for n feet: device tensors [n,3], [n,3], [n], [n], [n] -> p, v, a."""

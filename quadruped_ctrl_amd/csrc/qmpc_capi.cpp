@@ -24,6 +24,8 @@ extern "C" hipError_t qmpc_launch_leg_kin(const float geom[4], const float* q, c
                                           float* v, int batch, hipStream_t stream);
 extern "C" hipError_t qmpc_launch_leg_cmd(const float geom[4], const qmpc_leg_command* c, float* tau, float* q_des,
                                           int batch, hipStream_t stream);
+extern "C" hipError_t qmpc_launch_kf(const qmpc_kf_state* st, const float hip[3], int batch, hipStream_t stream);
+extern "C" hipError_t qmpc_launch_kf_init(float* xhat, float* P, int batch, hipStream_t stream);
 extern "C" hipError_t qmpc_launch_swing(const float* p0, const float* pf, const float* height, const float* phase,
                                         const float* swing_time, float* p, float* v, float* a, int n_feet,
                                         hipStream_t stream);
@@ -111,7 +113,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 9; }
+int qmpc_abi_version(void) { return 10; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -599,6 +601,26 @@ int qmpc_swing_trajectory(qmpc_handle c, int n_feet, const float* p0, const floa
   if (n_feet == 0) return QMPC_OK;
   DeviceGuard g(c->device);
   HIP_TRY(c, qmpc_launch_swing(p0, pf, height, phase, swing_time, p, v, a, n_feet, (hipStream_t)stream));
+  return QMPC_OK;
+}
+
+int qmpc_kf_init(qmpc_handle c, int batch, float* xhat, float* P, void* stream) {
+  if (!c || !xhat || !P || batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, qmpc_launch_kf_init(xhat, P, batch, (hipStream_t)stream));
+  return QMPC_OK;
+}
+
+int qmpc_kf_step(qmpc_handle c, int batch, const qmpc_kf_state* st, void* stream) {
+  if (!c || !st || batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (!st->xhat || !st->P || !st->r_body || !st->a_world || !st->omega_body || !st->contact_phase || !st->leg_p ||
+      !st->leg_v || !st->position || !st->v_world)
+    return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  DeviceGuard g(c->device);
+  static const float hip[3] = {0.19f, 0.049f, 0.f};  // _abadLocation (MiniCheetah.h:25-26,105)
+  HIP_TRY(c, qmpc_launch_kf(st, hip, batch, (hipStream_t)stream));
   return QMPC_OK;
 }
 

@@ -339,7 +339,7 @@ struct Smem {
 // sum of rank-1 events; fastest, capacity-limited by the LDS pool), false = the
 // Schur form that never overflows.  Both are run by wave 0 alone.  Returns true
 // when the robot must be re-run with the other engine.
-template <int RB, bool V5, bool CMD, bool ADMM = false>
+template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false>
 __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
@@ -619,7 +619,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         if (P.iters) P.iters[rid] = 0;
         if (cmdm) cmd_finish_state();
       }
-      if (P.ws && tid < QMPC_WS_STRIDE) P.ws[(size_t)rid * QMPC_WS_STRIDE + tid] = -1;
+      if (WARM && P.ws && tid < QMPC_WS_STRIDE) P.ws[(size_t)rid * QMPC_WS_STRIDE + tid] = -1;
     } else if (P.next_list) {
       if (tid == 0) {
         const int slot = atomicAdd(P.next_count, 1);
@@ -1305,7 +1305,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // remains is a genuine Goldfarb-Idnani state (x optimal on W, multipliers >= 0) and the normal
       // iteration takes over.  The answer is the same unique minimiser; only the path is shorter.
       int cand = -1;
-      if (P.ws && lane < KS) {
+      if (WARM && P.ws && lane < KS) {
         const int eg = P.ws[(size_t)rid * QMPC_WS_STRIDE + lane];  // global id 5 * (4 step + foot) + type
         const int kg = (eg >= 0 ? eg / 5 : 0) - 4 * P.ws_shift;
         if (eg >= 0 && kg >= 0 && kg < nfs) {
@@ -1313,8 +1313,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (sl != 0xff) cand = 5 * sl + (eg - 5 * (eg / 5));
         }
       }
-      unsigned long long cmask = __ballot(cand >= 0);
-      bool forced = false, fixneg = (cmask != 0ull);
+      // (WARM is a separate instantiation: the cold kernel carries none of this)
+      unsigned long long cmask = WARM ? __ballot(cand >= 0) : 0ull;
+      bool forced = false, fixneg = WARM && (cmask != 0ull);
       int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
       double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
       int rbl[RE];
@@ -1424,7 +1425,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         pty = __builtin_amdgcn_readfirstlane(pty);
         pj1 = __builtin_amdgcn_readfirstlane(pj1);
         pj2 = __builtin_amdgcn_readfirstlane(pj2);
-        if (uni(need_p) && cmask != 0ull) {
+        if (WARM && uni(need_p) && cmask != 0ull) {
           // ---- warm start: next candidate of the previous working set, forced
           const int cl = __ffsll((long long)cmask) - 1;
           cmask &= cmask - 1ull;
@@ -1436,7 +1437,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           lp = 0.0;
           need_p = false;
           forced = true;
-        } else if (uni(need_p) && fixneg) {
+        } else if (WARM && uni(need_p) && fixneg) {
           // ---- warm start, second phase: a candidate whose multiplier is negative does not belong to
           // the working set -- remove it (one drop event) and move to the minimiser without it
           const unsigned long long nm = __ballot(wcid >= 0 && lam < 0.0);
@@ -1528,19 +1529,19 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
         if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
         const bool dep = uni(!(delta > 1e-11 * cn));
-        if (forced && dep) {  // a candidate that depends on the ones already added: skip it
+        if (WARM && forced && dep) {  // a candidate that depends on the ones already added: skip it
           need_p = true;
           continue;
         }
         const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
         double ratio = __builtin_inf();
-        if (!forced && wcid >= 0 && rw > 0.0) {
+        if (!(WARM && forced) && wcid >= 0 && rw > 0.0) {
           const double qv = lam * fast_rcp(rw);
           ratio = qv > 0.0 ? qv : 0.0;
         }
         double t1 = __builtin_inf();
         int l = -1;
-        if (khw > 0 && !forced) {
+        if (khw > 0 && !(WARM && forced)) {
           t1 = wave_min_pos_f64(ratio);
           if (uni(t1 < __builtin_inf())) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
         }
@@ -1619,7 +1620,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (P.iters) P.iters[rid] = iters;
           if (cmdm) cmd_finish_state();
         }
-        if (P.ws)  // the final working set, as global ids, for the next cycle's warm start
+        if (WARM && P.ws)  // the final working set, as global ids, for the next cycle's warm start
           P.ws[(size_t)rid * QMPC_WS_STRIDE + lane] =
               (lane < KS && wcid >= 0 && !dead) ? 5 * (int)S.sidx[wcid / 5] + (wcid % 5) : -1;
         if (cmdm && P.f_ff) {
@@ -2018,7 +2019,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       if (P.iters) P.iters[rid] = iters;
       if (cmdm) cmd_finish_state();
     }
-    if (P.ws)  // (this engine always starts cold; it still leaves its working set for the next cycle)
+    if (WARM && P.ws)  // (this engine always starts cold; it still leaves its working set for the next cycle)
       P.ws[(size_t)rid * QMPC_WS_STRIDE + lane] =
           (wcid[0] >= 0 && !dead) ? 5 * (int)S.sidx[wcid[0] / 5] + (wcid[0] % 5) : -1;
     if (cmdm && P.f_ff) {
@@ -2049,7 +2050,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 // The list counters are ping-ponged between consecutive solve calls: the
 // class-1 kernel of call N clears the set that call N+1 will use, so no memset
 // and no host round trip is needed.
-template <int RB, bool CMD>
+template <int RB, bool CMD, bool WARM = false>
 __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
@@ -2067,18 +2068,18 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
     // projected-inverse engine first; the (rare) robot that runs out of pool is
     // solved again from scratch with the Schur-form engine, which cannot overflow
-    if (solve_one<RB, true, CMD>(rid, (int)threadIdx.x, S, P)) {
+    if (solve_one<RB, true, CMD, false, WARM>(rid, (int)threadIdx.x, S, P)) {
       __syncthreads();
       // opaque thread id: without it the compiler keeps per-thread values of the
       // first run alive (spilled to scratch by EVERY workgroup) for this rare second run
       int tid2 = (int)threadIdx.x;
       asm volatile("" : "+v"(tid2));
-      solve_one<RB, false, CMD>(rid, tid2, S, P);
+      solve_one<RB, false, CMD, false, WARM>(rid, tid2, S, P);
       __syncthreads();
       if (threadIdx.x == 0) P.status[rid] |= QMPC_DEV_ST_FALLBACK;  // informational
     }
   } else {
-    solve_one<RB, false, CMD>(rid, (int)threadIdx.x, S, P);
+    solve_one<RB, false, CMD, false, WARM>(rid, (int)threadIdx.x, S, P);
   }
 }
 
@@ -2115,6 +2116,9 @@ hipError_t prepare_one() {
 }
 template <int RB>
 hipError_t prepare_admm() {
+  hipError_t e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<RB, false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<RB>));
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)qmpc_admm_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)sizeof(Smem<RB>));
 }
@@ -2122,6 +2126,8 @@ template <int RB>
 void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
   if (P->admm_mode)
     hipLaunchKernelGGL((qmpc_admm_kernel<RB>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
+  else if (P->ws && !cmd)  // warm start across cycles: its own instantiation (record mode)
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, true>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
   else if (cmd)
     hipLaunchKernelGGL((qmpc_solve_kernel<RB, true>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
   else

@@ -347,3 +347,38 @@ class Rollout:
         self.it = (self.it + 1) % self.h
         after = self.contact_table()[:, :4] != 0
         self._place(before & ~after)          # feet that just lifted off: re-placed under the hips
+
+
+def make_kf_stream(batch, steps, seed=5):
+    """Synthetic estimator inputs for the Kalman filter (include/qmpc.h qmpc_kf_state): robots moving at a
+    constant world velocity with a yawed body, feet planted (so the leg kinematics see the body move
+    over them), gait phases sweeping 0..1 per leg, accelerometer = gravity + noise.  Yields one dict per
+    control tick (dt = 2 ms) plus the true position / velocity."""
+    rng = np.random.default_rng(SEED0 + 3000 + seed)
+    f32 = np.float32
+    B = batch
+    yaw = rng.uniform(-1, 1, B)
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    R = np.zeros((B, 3, 3))                     # rBody: world -> body
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = cy, sy, -sy, cy, 1.0
+    vel = np.concatenate([rng.normal(0, 0.3, (B, 2)), np.zeros((B, 1))], 1)
+    pos0 = np.array([0, 0, 0.29]) + rng.normal(0, 0.01, (B, 3))
+    hips = np.array([[.19, -.049, 0], [.19, .049, 0], [-.19, -.049, 0], [-.19, .049, 0]])
+    feet_w = pos0[:, None, :] + np.einsum("bji,lj->bli", R, hips + np.array([0, 0, -0.29]))  # under the hips, on the ground
+    feet_w[:, :, 2] = 0.0
+    phase0 = rng.random((B, 4))
+    out = []
+    for t in range(steps):
+        pos = pos0 + vel * 0.002 * t
+        rel_w = feet_w - pos[:, None, :]                              # foot relative to the body, world frame
+        p_body = np.einsum("bij,blj->bli", R, rel_w) - hips[None]     # hip frame (legControllerData.p)
+        v_body = np.einsum("bij,bj->bi", R, -vel)[:, None, :].repeat(4, 1)
+        out.append({
+            "r_body": R.reshape(B, 9).astype(f32),
+            "a_world": (np.array([0, 0, 9.81]) + rng.normal(0, 0.05, (B, 3))).astype(f32),
+            "omega_body": rng.normal(0, 0.01, (B, 3)).astype(f32),
+            "contact_phase": ((phase0 + 0.004 * t) % 1.0).astype(f32),
+            "leg_p": (p_body + rng.normal(0, 0.001, (B, 4, 3))).reshape(B, 12).astype(f32),
+            "leg_v": (v_body + rng.normal(0, 0.02, (B, 4, 3))).reshape(B, 12).astype(f32),
+            "true_position": pos, "true_velocity": vel})
+    return out

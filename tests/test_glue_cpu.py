@@ -83,3 +83,25 @@ def test_swing_bezier_properties():
     dt = (2 * dph * s["swing_time"])[:, None]
     assert np.abs((pp - pm)[ok] / dt[ok] - v[ok]).max() < 2e-2
     assert np.abs((vp - vm)[ok] / dt[ok] - a[ok]).max() < 2.0
+
+
+def test_kalman_filter_restatement_tracks_the_truth():
+    """oracle_kf_step (PositionVelocityEstimator.cpp:66-221 restated): fed consistent leg kinematics of robots
+    gliding over planted feet, the filter's velocity converges to the true velocity and its height to the true
+    height; P stays symmetric positive definite."""
+    stream = W.make_kf_stream(32, 400)
+    xhat, P = G.kf_init(32)
+    for s in stream:
+        pos, vw, vb = G.kf_step(xhat, P, s["r_body"], s["a_world"], s["omega_body"], s["contact_phase"], s["leg_p"], s["leg_v"])
+    tv, tp = stream[-1]["true_velocity"], stream[-1]["true_position"]
+    assert np.abs(vw - tv).max() < 0.03
+    assert np.abs(pos[:, 2] - tp[:, 2]).max() < 0.01
+    # x, y are only observable relative to the feet: the estimate moves with the true displacement
+    d_est = pos[:, :2] - 0.0
+    d_true = tp[:, :2] - stream[0]["true_position"][:, :2]
+    assert np.abs((d_est - d_est.mean(0)) - (d_true - d_true.mean(0))).max() < 0.2
+    Pm = P.reshape(32, 18, 18)
+    assert np.abs(Pm - Pm.transpose(0, 2, 1)).max() == 0.0
+    assert np.linalg.eigvalsh(Pm.astype(np.float64)).min() > 0
+    assert np.array_equal(vb, np.einsum("bij,bj->bi", s["r_body"].reshape(32, 3, 3), vw).astype(np.float32)) or \
+        np.abs(vb - np.einsum("bij,bj->bi", s["r_body"].reshape(32, 3, 3).astype(np.float64), vw)).max() < 1e-6

@@ -112,3 +112,46 @@ def test_glue_argument_errors(mpc_factory):
     assert m.lib.qmpc_swing_trajectory(m.h, 17, *([None] * 9)) == 1       # > 4 * max_batch feet
     assert m.lib.qmpc_leg_kinematics(m.h, 0, None, None, None, None, None, None) == 1
     assert m.lib.qmpc_set_leg_geometry(m.h, 0.062, -1.0, 0.195, 0.004) == 1
+
+
+@pytest.mark.parametrize("B", [1, 7, 512])
+def test_kalman_filter_bit_exact(B, mpc_factory):
+    """qmpc_kf_init / qmpc_kf_step against the restatement over a stream of control ticks: every lane computes
+    its elements with the restatement's operations in the restatement's order (no transcendentals in the
+    filter), so state, covariance and outputs are BIT-IDENTICAL after every step."""
+    import torch
+    m = _mpc(mpc_factory, B)
+    stream = W.make_kf_stream(B, 25, seed=B)
+    xr, Pr = G.kf_init(B)
+    xd, Pd = m.kf_init(B)
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy(), xr) and np.array_equal(Pd.cpu().numpy(), Pr)
+    keys = ("r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v")
+    for t, s in enumerate(stream):
+        pr, vwr, vbr = G.kf_step(xr, Pr, *(s[k] for k in keys))
+        pd, vwd, vbd = m.kf_step(xd, Pd, *(m._dev32(s[k]) for k in keys))
+        torch.cuda.synchronize()
+        assert np.array_equal(xd.cpu().numpy(), xr), t
+        assert np.array_equal(Pd.cpu().numpy(), Pr), t
+        assert np.array_equal(pd.cpu().numpy(), pr) and np.array_equal(vwd.cpu().numpy(), vwr) and np.array_equal(vbd.cpu().numpy(), vbr)
+    assert np.isfinite(Pr).all() and np.abs(vwr).max() < 5.0
+
+
+def test_estimator_to_mpc_chain_on_device(mpc_factory):
+    """The per-tick glue chained on the device: joint angles -> leg kinematics -> Kalman filter -> the MPC record's
+    position / velocity rows, without a host round trip in between."""
+    import torch
+    B = 64
+    m = _mpc(mpc_factory, B)
+    s = W.make_leg_states(B, seed=8)
+    q, qd = m._dev32(s["q"]), m._dev32(s["qd"])
+    J, p, v = m.leg_kinematics(q, qd)
+    xhat, P = m.kf_init(B)
+    st = W.make_kf_stream(B, 1, seed=2)[0]
+    pos, vw, vb = m.kf_step(xhat, P, m._dev32(st["r_body"]), m._dev32(st["a_world"]), m._dev32(st["omega_body"]),
+                            m._dev32(st["contact_phase"]), p, v)
+    torch.cuda.synchronize()
+    xr, Pr = G.kf_init(B)
+    Jr, pr, vr = G.leg_update(s["q"], s["qd"])
+    pos_r, vw_r, _ = G.kf_step(xr, Pr, st["r_body"], st["a_world"], st["omega_body"], st["contact_phase"], pr, vr)
+    assert np.abs(pos.cpu().numpy() - pos_r).max() < 1e-5 and np.abs(vw.cpu().numpy() - vw_r).max() < 1e-4
