@@ -123,6 +123,25 @@ int qmpc_set_robot(qmpc_handle h, double mass, const double ibody_diag[3],
  * SolverMPC.cpp:435) and the constraint-violation tolerance [N]. */
 int qmpc_settings(qmpc_handle h, int max_iter, double tol);
 
+/* The reference's SPARSE formulation: SparseCMPC (src/MPC_Ctrl/SparseCMPC.cpp:31-73) keeps
+ * the 12 states of every horizon step as variables, writes the dynamics as equality rows and hands the
+ * sparse QP to OSQP (OsqpTriples.cpp:57-142).  Its discrete model differs from the dense path's:
+ * A_d = expm(A dt) = I + A dt (A^2 = 0 without the gravity state), B_d = B dt (SparseCMPC_Math.cpp:25 --
+ * not the matching block of the matrix exponential), gravity -9.81 added as g dt to the velocity rows once
+ * per step (:41-42, :214, :268).  Eliminating the states through those equality rows gives a condensed QP
+ * with the same block structure as the dense path's -- A_d^d B_d = dt B + d dt^2 A B, i.e. only the second
+ * coefficient family and the free response change -- so QMPC_MODEL_SPARSE solves SparseCMPC's QP with the
+ * same closed-form assembly and the same exact solver, and returns its exact minimiser (the reference's
+ * OSQP run stops at eps = 1e-5, a few per cent from it on the small force components).  Set the gravity
+ * with qmpc_set_robot(..., -9.81) and pass SparseCMPC's own mu / weights / alpha (initSparseMPC,
+ * ConvexMPCLocomotion.cpp:732-756: mu 1.0, weights 0.25 0.25 10 2 2 20 0 0 0.3 0.2 0.2 0.2); x_drag
+ * is ignored by this model; yaw is the quaternion's (SparseCMPC.cpp:99).  Horizons up to
+ * QMPC_MAX_HORIZON like every other entry point (the long horizons that motivate a sparse solver on the
+ * CPU are not what the reference uses it with: solveSparseMPC runs horizonLength = 10..16). */
+#define QMPC_MODEL_DENSE 0
+#define QMPC_MODEL_SPARSE 1
+int qmpc_set_model(qmpc_handle h, int model);
+
 /* The reference's alternate solver: update_solver_settings(..., use_jcqp) with
  * use_jcqp = 1 or 2 makes solve_mpc run JCQP's QpProblem<double>::runFromDense
  * (src/JCQP/QpProblem.cpp:178-269) -- an OSQP-style ADMM from a cold start, stopped when

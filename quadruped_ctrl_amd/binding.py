@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 10              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 11              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_NONFINITE = 32
 ST_ERROR_MASK = 15 | 32
@@ -23,7 +23,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
-           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step"]
+           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
@@ -97,6 +97,7 @@ def load_library():
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.qmpc_set_model.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_kf_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_kf_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(KfState), C.c_void_p]
         lib.qmpc_settings_jcqp.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 4
@@ -167,6 +168,10 @@ class BatchedConvexMPC:
     def set_robot(self, mass, ibody, gravity):
         arr = (C.c_double * 3)(*ibody)
         self._check(self.lib.qmpc_set_robot(self.h, mass, arr, gravity), "qmpc_set_robot")
+
+    def set_model(self, model):
+        """0 = the dense path's zero-order-hold model, 1 = SparseCMPC's (QMPC_MODEL_SPARSE)."""
+        self._check(self.lib.qmpc_set_model(self.h, int(model)), "qmpc_set_model")
 
     def settings_jcqp(self, use_jcqp, max_iter=10000, rho=1e-7, sigma=1e-8, alpha=1.5, terminate=0.1):
         """The reference's JCQP/ADMM alternate (update_solver_settings' use_jcqp = 1 / 2); 0 = exact solve.

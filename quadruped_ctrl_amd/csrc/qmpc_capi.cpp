@@ -69,8 +69,9 @@ struct qmpc_ctx {
   hipEvent_t host_ev = nullptr;
   void* h_pin = nullptr;
   size_t pin_bytes = 0;
-  double tab_dt = -1.0;  // (dt, horizon) the tables in d_tables were built for
-  int tab_h = -1;
+  double tab_dt = -1.0;  // (dt, horizon, model) the tables in d_tables were built for
+  int tab_h = -1, tab_model = -1;
+  int model = 0;         // QMPC_MODEL_*
   std::string err;
 };
 
@@ -113,7 +114,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 10; }
+int qmpc_abi_version(void) { return 11; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -170,7 +171,7 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   const int h = horizon;
   // the tables depend on (dt, horizon) only: the reference's caller repeats setup_problem with the
   // same values before every solve (ConvexMPCLocomotion.cpp:630), which costs nothing here
-  if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h) return QMPC_OK;
+  if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h && c->tab_model == c->model) return QMPC_OK;
   // coefficient tables (see qmpc_device.h); A_ct^3 = 0 makes
   // Adt^d Bdt = dt B + c_d A B + e_d A^2 B exact.
   std::vector<double> t(3 * h + 9 * h * h);
@@ -179,9 +180,15 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   const double d1 = c->dt;
   for (int d = 0; d < h; ++d) {
     coef[0 * h + d] = d1;
-    coef[1 * h + d] = (2.0 * d + 1.0) * d1 * d1 / 2.0;
     const double dp = d + 1.0;
-    coef[2 * h + d] = (dp * dp * dp - (double)d * d * d) * d1 * d1 * d1 / 6.0;
+    if (c->model == QMPC_MODEL_SPARSE) {
+      // SparseCMPC: A_d^d B_d = (I + d dt A) B dt = dt B + d dt^2 A B  (A^2 = 0; no drag term)
+      coef[1 * h + d] = (double)d * d1 * d1;
+      coef[2 * h + d] = 0.0;
+    } else {
+      coef[1 * h + d] = (2.0 * d + 1.0) * d1 * d1 / 2.0;
+      coef[2 * h + d] = (dp * dp * dp - (double)d * d * d) * d1 * d1 * d1 / 6.0;
+    }
   }
   for (int p = 0; p < 3; ++p)
     for (int q = 0; q < 3; ++q)
@@ -197,6 +204,7 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   HIP_TRY(c, hipMemcpy(c->d_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
   c->tab_dt = c->dt;
   c->tab_h = h;
+  c->tab_model = c->model;
   c->is_setup = true;
   return QMPC_OK;
 }
@@ -227,6 +235,15 @@ int qmpc_set_max_stance(qmpc_handle c, int max_stance_footsteps) {
 int qmpc_set_min_stance(qmpc_handle c, int min_stance_footsteps) {
   if (!c || min_stance_footsteps < 0) return QMPC_ERR_ARG;
   c->min_stance = min_stance_footsteps;
+  return QMPC_OK;
+}
+
+int qmpc_set_model(qmpc_handle c, int model) {
+  if (!c || (model != QMPC_MODEL_DENSE && model != QMPC_MODEL_SPARSE)) return QMPC_ERR_ARG;
+  if (model != c->model) {
+    c->model = model;
+    if (c->is_setup) return qmpc_setup(c, c->dt, c->horizon, c->mu, c->f_max);  // rebuild the tables
+  }
   return QMPC_OK;
 }
 
@@ -340,6 +357,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.inv_mass = 1.0 / c->mass;
   for (int k = 0; k < 3; ++k) P.inv_ibody[k] = 1.0 / c->ibody[k];
   P.gravity = c->gravity;
+  P.model = c->model;
   P.coef = c->d_tables;
   P.ctab = c->d_tables + 3 * h;
   P.max_iter = c->max_iter;

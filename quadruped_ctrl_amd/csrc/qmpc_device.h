@@ -44,6 +44,9 @@ struct QmpcParams {
   double dt, mu_inv, inv_fr_norm, f_max;
   double mass, ibody[3], gravity;
   double inv_mass, inv_ibody[3];  // host-side reciprocals (no fp64 divisions in the kernel prologue)
+  // discretisation: 0 = the dense path's exact zero-order hold with the gravity state (SolverMPC.cpp:87-125),
+  // 1 = SparseCMPC's (SparseCMPC_Math.cpp:6-28: A_d = expm(A dt) = I + A dt, B_d = B dt, g dt added per step)
+  int model;
   // batch-constant tables built at qmpc_setup():
   //   coef[p][d]   p<3, d<h     dt, (2d+1)dt^2/2, ((d+1)^3-d^3)dt^3/6
   //   ctab[pq][i][j] pq<9       sum_{k>=max(i,j)} coef_p(k-i) coef_q(k-j)

@@ -565,7 +565,12 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         val = (double)ang + rate * t;  // Theta' = R_yaw^T omega
       } else if (row < 6) {
         val = (double)g_p + (double)(row == 3 ? g_v[0] : (row == 4 ? g_v[1] : g_v[2])) * t;
-        if (row == 5) val += 0.5 * (PK.gravity + x_drag * (double)g_v[0]) * t * t;  // A(11,12), A(11,9)
+        if (row == 5) {
+          // ZOH model: 1/2 g t^2 (A(11,12), A(11,9)); SparseCMPC's model adds g dt to the velocity once per step
+          // and integrates positions with explicit Euler: g dt^2 n (n - 1) / 2 = 1/2 g (t^2 - t dt)
+          val += (PK.model == 1) ? 0.5 * PK.gravity * (t * t - t * PK.dt)
+                                 : 0.5 * (PK.gravity + x_drag * (double)g_v[0]) * t * t;
+        }
       } else if (row < 9) {
         val = (double)(row == 6 ? g_w[0] : (row == 7 ? g_w[1] : g_w[2]));
       } else {
@@ -682,7 +687,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         S1 = S1 + S0;
         S0 = S0 + ek[st];
         Aa.s[0][st * 12 + row] = dt1 * S0;
-        Aa.s[1][st * 12 + row] = dt2 * S1 + (0.5 * dt2) * S0;
+        // coef_1(d) = (2d + 1) dt^2 / 2 (exact zero-order hold) or d dt^2 (SparseCMPC: B_d = B dt, c2d)
+        Aa.s[1][st * 12 + row] = (P.model == 1) ? dt2 * S1 : dt2 * S1 + (0.5 * dt2) * S0;
         Aa.s[2][st * 12 + row] = (0.5 * dt3) * (S2 + S1) + (dt3 / 6.0) * S0;
       }
     }

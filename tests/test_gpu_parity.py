@@ -983,3 +983,73 @@ def test_warm_start_rollout_same_answer(gait, h, mpc_factory):
     warm.warm_start(None)
     b = ro.record()
     assert np.array_equal(warm.solve(b, full=True)["soln"], cold.solve(b, full=True)["soln"])
+
+
+def _sparse_exact(b, i):
+    """Exact minimiser of SparseCMPC's QP for robot i: the restated sparse QP condensed (oracle/sparse_model.py)
+    and solved by the reference's qpOASES.  -> q_soln-like [12h] (zeros on swing foot-steps)."""
+    from oracle import sparse_model as SM
+    prob = SM.from_batch(b, i, weights=b["weights"][i].astype(np.float64), alpha=float(b["alpha"][i]), mu=b["mu"],
+                         f_max=b["f_max"])
+    H, g = SM.condensed(prob, weights=b["weights"][i].astype(np.float64), alpha=float(b["alpha"][i]),
+                        traj=b["traj"][i].reshape(-1, 12))
+    nb = len(prob["blocks"])
+    mi = 1.0 / b["mu"]
+    Ac = np.zeros((5 * nb, 3 * nb))
+    lb, ub = np.zeros(5 * nb), np.full(5 * nb, 1e15)
+    for k in range(nb):
+        for t, (ax, sg) in enumerate(((0, mi), (0, -mi), (1, mi), (1, -mi))):
+            Ac[5 * k + t, 3 * k + ax] = sg
+            Ac[5 * k + t, 3 * k + 2] = 1
+        Ac[5 * k + 4, 3 * k + 2] = 1
+        ub[5 * k + 4] = b["f_max"]
+    out = np.zeros(12 * b["horizon"])
+    if nb:
+        xq, _, _, rc, irc = O.qpoases(H, g, Ac, lb, ub, nwsr=5000)
+        assert rc == 0 and irc == 0
+        for k, (foot, step) in enumerate(prob["blocks"]):
+            out[12 * step + 3 * foot:12 * step + 3 * foot + 3] = xq[3 * k:3 * k + 3]
+    return out, prob
+
+
+@pytest.mark.parametrize("mk", [lambda: W.make_config(2, batch=10), lambda: W.make_config(4, batch=10),
+                                lambda: W.make_trot(6, 16), lambda: W.make_standing(3, 14, calm=True)],
+                         ids=["mixed_h10", "stairs_random_h10", "trot_h16", "standing_h14"])
+def test_sparse_formulation_model(mk, mpc_factory):
+    """QMPC_MODEL_SPARSE returns the exact minimiser of the reference's SPARSE formulation
+    (SparseCMPC.cpp:31-73 with SparseCMPC_Math.cpp's discretisation), with SparseCMPC's own parameters
+    (mu = 1, its weights, gravity -9.81).  Checked against (a) that QP condensed and solved by the
+    reference's qpOASES (<= 2e-6: two routes to one minimiser; the kernel evaluates the Euler angles in
+    float), (b) the reference's own OSQP 0.5.0 run at tight tolerances (<= 1e-5), and (c) at the
+    reference's eps = 1e-5, where OSQP itself is only within a few per cent."""
+    from oracle import sparse_model as SM
+    b = mk()
+    B, h = b["batch"], b["horizon"]
+    b["mu"] = SM.SPARSE_MU
+    b["weights"] = np.tile(SM.SPARSE_WEIGHTS.astype(np.float32), (B, 1))
+    m = mpc_factory(b)
+    m.set_robot(9.0, (0.07, 0.26, 0.242), -9.81)
+    dense = m.solve(b, full=True)["soln"]
+    m.set_model(1)
+    res = m.solve(b, full=True)
+    assert ((res["status"] & 47) == 0).all()
+    worst_exact = worst_tight = worst_ref = 0.0
+    for i in range(B):
+        want, prob = _sparse_exact(b, i)
+        scale = max(np.abs(want).max(), 1.0)
+        worst_exact = max(worst_exact, np.abs(res["soln"][i] - want).max() / scale)
+        if i < 4 and len(prob["blocks"]):
+            T = prob["T"]
+            pick = lambda x: np.concatenate([x[12 * T + 3 * k:12 * T + 3 * k + 3] for k in range(len(prob["blocks"]))])
+            mine = np.concatenate([res["soln"][i][12 * st + 3 * ft:12 * st + 3 * ft + 3] for ft, st in prob["blocks"]])
+            xt, st1, _ = SM.osqp(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], eps=1e-10, max_iter=400000)
+            xr, st2, _ = SM.osqp(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"])
+            assert st1 == 1 and st2 == 1
+            worst_tight = max(worst_tight, np.abs(pick(xt) - mine).max() / scale)
+            worst_ref = max(worst_ref, np.abs(pick(xr) - mine).max() / scale)
+    print(f"h={h}: vs condensed qpOASES {worst_exact:.2e}, vs OSQP tight {worst_tight:.2e}, vs OSQP at the reference's eps {worst_ref:.2e}")
+    assert worst_exact < 2e-6 and worst_tight < 1e-5 and worst_ref < 0.2
+    # it is a different model: the answer differs from the dense path's at the per-cent level, and going back restores it
+    assert np.abs(res["soln"] - dense).max() / np.abs(dense).max() > 1e-4
+    m.set_model(0)
+    assert np.array_equal(m.solve(b, full=True)["soln"], dense)

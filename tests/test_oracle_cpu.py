@@ -192,3 +192,41 @@ def test_noise_floor_module_and_fixture():
     fam = json.load(open(os.path.join(ROOT, "tests", "golden", "noise_floor.json")))["families"]
     assert fam["cfg1_trot_h10"]["fp64_to_float_first_step"]["max"] < 1e-4
     assert fam["trot_h16_96"]["fp64_to_float_first_step"]["max"] > 1e-4
+
+
+def test_sparse_formulation_restatement_and_reference_osqp():
+    """SURVEY 8f-3 checker: the SparseCMPC restatement (oracle/sparse_model.py) solved by the REFERENCE's own OSQP
+    0.5.0 (oracle/_ref/libosqp_ref.so) -- (i) the discrete model of c2d is what the restatement says it is
+    (expm(A dt) = I + A dt exactly, B_d = B dt), (ii) driven to tight tolerances OSQP reaches the minimiser of
+    the condensed-equivalent QP solved by the reference's qpOASES (two independent solvers, two formulations),
+    (iii) at the reference's own eps = 1e-5 it stops a few per cent short of it."""
+    from oracle import sparse_model as SM
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libosqp_ref.so")):
+        pytest.skip("no _ref")
+    b = W.make_config(4, batch=3)
+    for i in range(3):
+        prob = SM.from_batch(b, i)
+        A_ct = np.zeros((12, 12))
+        A_ct[3, 9] = A_ct[4, 10] = A_ct[5, 11] = 1
+        c, s = np.cos(prob["x0"][2]), np.sin(prob["x0"][2])
+        A_ct[0:3, 6:9] = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
+        assert np.abs(prob["Ad"][0] - (np.eye(12) + A_ct * prob["dts"][0])).max() < 1e-15
+        x_ref, st, it = SM.osqp(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"])           # reference settings
+        x_tight, st2, _ = SM.osqp(prob["P"], prob["q"], prob["A"], prob["l"], prob["u"], eps=1e-10, max_iter=400000)
+        assert st == 1 and st2 == 1
+        H, g = SM.condensed(prob, traj=b["traj"][i].reshape(-1, 12))
+        nb = len(prob["blocks"])
+        Ac = np.zeros((5 * nb, 3 * nb))
+        lb, ub = np.zeros(5 * nb), np.full(5 * nb, 1e15)
+        for k in range(nb):
+            for t, (ax, sg) in enumerate(((0, 1.0), (0, -1.0), (1, 1.0), (1, -1.0))):
+                Ac[5 * k + t, 3 * k + ax] = sg
+                Ac[5 * k + t, 3 * k + 2] = 1
+            Ac[5 * k + 4, 3 * k + 2] = 1
+            ub[5 * k + 4] = SM.SPARSE_FMAX
+        xq, _, _, rc, irc = O.qpoases(H, g, Ac, lb, ub, nwsr=2000)
+        assert rc == 0 and irc == 0
+        u_tight = x_tight[12 * prob["T"]:]
+        scale = max(np.abs(xq).max(), 1.0)
+        assert np.abs(u_tight - xq).max() / scale < 1e-6
+        assert 1e-5 < np.abs(x_ref[12 * prob["T"]:] - xq).max() / scale < 0.2
