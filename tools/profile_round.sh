@@ -24,4 +24,10 @@ run standing_h10 --workload standing --horizon 10
 run standing_h14 --workload standing --horizon 14
 run standing_h16 --workload standing --horizon 16
 run trot_h16 --config 3
+# bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
+for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
+for b in 256 4096 16384 65536; do python $R/bench.py --steps 100 --batch $b --no-cpu-baseline --no-pipelined > $OUT/bench_cfg1_b$b.json 2>/dev/null; done
+python $R/bench.py --steps 100 --caller-side fused --no-cpu-baseline > $OUT/bench_caller_fused.json 2>/dev/null
+python $R/tools/shim_latency.py > $OUT/shim_latency.json 2> $OUT/shim_latency.err
+python $R/tools/warm_rollout.py --cycles 30 > $OUT/warm_rollout.json 2> $OUT/warm_rollout.err
 ls -la $OUT
