@@ -1,7 +1,7 @@
 """Fold a tools/pmc.sh run into profiles/pmc_latest.json (what bench.py's roofline.traffic and
 roofline.executed_* read), stamped with the hash of the kernel source it was collected on.
 
-    python tools/pmc_to_latest.py gpurun_out/<dir> <workload-key> <batch> <profile-name>
+    python tools/pmc_to_latest.py <pmc_summary.json | its directory> <workload-key> <batch> <profile-name>
 e.g. python tools/pmc_to_latest.py gpurun_out/r02_pmc_cfg1 config1 1024 profiles/r02_a_pmc_summary.json
 """
 import json
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402
 
 src, key, batch, prof = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-summ = json.load(open(os.path.join(src, "pmc_summary.json")))
+summ = json.load(open(src if os.path.isfile(src) else os.path.join(src, "pmc_summary.json")))
 # the dominant solve kernel of the run: the one with the most busy cycles
 name, d = max(((k, v) for k, v in summ.items() if "qmpc_solve_kernel" in k), key=lambda kv: kv[1].get("SQ_WAVE_CYCLES", 0))
 fetch, write = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)     # KiB per dispatch

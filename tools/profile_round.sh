@@ -17,7 +17,7 @@ run() {  # name, bench args...
   find $OUT/stats_$name -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$name.csv \;
   bash $R/tools/pmc.sh $TAG/pmc_$name --no-pipelined "$@" > $OUT/pmc_$name.log 2>&1
   cp $OUT/pmc_$name/pmc_summary.json $OUT/pmc_summary_$name.json 2>/dev/null
-  rm -rf $OUT/stats_$name $OUT/pmc_$name/p*
+  rm -rf $OUT/stats_$name $OUT/pmc_$name/p[0-9]*
 }
 run cfg1
 run standing_h10 --workload standing --horizon 10
