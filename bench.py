@@ -99,20 +99,30 @@ def cpu_baseline(b, spec, budget_s=8.0, all_cores=True):
                          f"SolverMPC.cpp assembly (fp32 dense) + the reference's own "
                          f"qpOASES 3.2.0 build (oracle/_ref), single thread, {dt:.1f} s of CPU time"}
         if all_cores:
-            cores = os.cpu_count() or 1
-            wspec = dict(spec, batch=min(spec["batch"], 256))
-            env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
-            procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", json.dumps(wspec), str(budget_s)],
-                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT, env=env)
-                     for _ in range(cores)]
-            outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in procs]
-            total = sum(o["solved"] for o in outs)
-            span = max(o["elapsed"] for o in outs)
-            res["all_cores"] = {"value": total / span, "unit": "QP solves/s", "cores": cores,
-                                "per_core": total / span / cores, "cpu_model": cpu_model(),
-                                "sample": f"{cores} worker processes (one per host core, the reference is "
-                                          f"single-threaded and non-reentrant), each looping over the first "
-                                          f"{wspec['batch']} robots for {budget_s:.0f} s"}
+            try:
+                cores = os.cpu_count() or 1
+                # one pass of a worker's robots ~1 s, so that every worker gets several passes into its window
+                per_solve = dt / (n * reps)
+                wspec = dict(spec, batch=int(min(256, max(8, 1.0 / max(per_solve, 1e-6)))))
+                env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+                procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", json.dumps(wspec), str(budget_s)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT, env=env)
+                         for _ in range(cores)]
+                outs = [json.loads(p.communicate(timeout=180)[0].strip().splitlines()[-1]) for p in procs]
+                total = sum(o["solved"] for o in outs)
+                span = max(o["elapsed"] for o in outs)
+                res["all_cores"] = {"value": total / span, "unit": "QP solves/s", "cores": cores,
+                                    "per_core": total / span / cores, "cpu_model": cpu_model(),
+                                    "sample": f"{cores} worker processes (one per host core, the reference is "
+                                              f"single-threaded and non-reentrant), each looping over the first "
+                                              f"{wspec['batch']} robots for {budget_s:.0f} s"}
+            except Exception as e:
+                res["all_cores"] = {"value": None, "error": repr(e)}
+                for p in procs:
+                    try:
+                        p.kill()
+                    except Exception:
+                        pass
         return res
     except Exception as e:  # baseline is reporting only; never fail the bench
         return {"value": None, "error": repr(e)}
