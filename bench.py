@@ -99,6 +99,7 @@ def cpu_baseline(b, spec, budget_s=8.0, all_cores=True):
                          f"SolverMPC.cpp assembly (fp32 dense) + the reference's own "
                          f"qpOASES 3.2.0 build (oracle/_ref), single thread, {dt:.1f} s of CPU time"}
         if all_cores:
+            procs = []
             try:
                 cores = os.cpu_count() or 1
                 # one pass of a worker's robots ~1 s, so that every worker gets several passes into its window
