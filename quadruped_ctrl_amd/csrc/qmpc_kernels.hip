@@ -963,9 +963,36 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     }
 #undef QMPC_PIN
   } else {
+    // Larger classes: a column group spans several waves (and in the 96-row class waves straddle two
+    // groups), so every thread still derives F for its own row -- but the 2x2 pivot block is inverted ONCE,
+    // by the thread that owns the first pivot row of the NEXT pair, as soon as its two pivot columns carry
+    // this step's update: it takes A[k1][k0], A[k1][k1] from its neighbour lane (the pair's rows are
+    // adjacent lanes of one 16-lane row), inverts through the determinant and publishes the three entries of
+    // P^-1 next to the pivot columns.  Every other thread used to repeat the determinant, the reciprocal and
+    // its two Newton steps itself: ~22 of ~95 instructions per thread and pair, in a loop that is bound by
+    // single-wave issue rate (same values, same operations: results are bit-identical).
+    auto lane_next = [](double x) __attribute__((always_inline)) {  // value of lane + 1 (DPP row_shl:1)
+      const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+      const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x101, 0xf, 0xf, false);
+      const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x101, 0xf, 0xf, false);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    auto publish_pinv = [&](double d0, double e, double d1p, int par) __attribute__((always_inline)) {
+      // 2x2 pivot block P = [[d0, e], [e, d1p]] inverted through its determinant:
+      // ONE reciprocal on the critical path.  P^-1 = idet [[d1p, -e], [-e, d0]].
+      const double det = __builtin_fma(d0, d1p, -e * e);
+      const double idet = fast_rcp(det);
+      double* pv = Sw.ubuf[par][0];
+      pv[0] = d1p * idet;  // +-entries of P^-1: i11, i01, i00
+      pv[1] = e * idet;
+      pv[2] = d0 * idet;
+      pv[3] = (!(d0 > 0.0) | !(det > 0.0)) ? 1.0 : 0.0;
+    };
     if (c == 0) {
       Sw.colbuf[0][0][i] = a[0];
       Sw.colbuf[0][1][i] = a[1];
+      const double e_n = lane_next(a[0]), d1_n = lane_next(a[1]);
+      if (i == 0) publish_pinv(a[0], e_n, d1_n, 0);
     }
     __syncthreads();
 #pragma unroll 1
@@ -985,16 +1012,10 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           const int m = k0 >> 1;
           const double* cb0 = Sw.colbuf[m & 1][0];
           const double* cb1 = Sw.colbuf[m & 1][1];
-          const double d0 = cb0[k0];
-          const double e = cb0[k1];  // A[k1][k0]
-          const double d1p = cb1[k1];
+          const double* pv = Sw.ubuf[m & 1][0];
           const double c0i = cb0[i], c1i = cb1[i];
-          // 2x2 pivot block P = [[d0, e], [e, d1p]] inverted through its determinant:
-          // ONE reciprocal on the critical path.  P^-1 = idet [[d1p, -e], [-e, d0]].
-          const double det = __builtin_fma(d0, d1p, -e * e);
-          notpd |= !(d0 > 0.0) | !(det > 0.0);
-          const double idet = fast_rcp(det);
-          const double i11 = d1p * idet, i01 = e * idet, i00 = d0 * idet;  // +-entries of P^-1
+          const double i11 = pv[0], i01 = pv[1], i00 = pv[2];  // +-entries of P^-1
+          notpd |= (pv[3] != 0.0);
           // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
           const double fg0 = __builtin_fma(i11, c0i, -i01 * c1i);
           const double fg1 = __builtin_fma(i00, c1i, -i01 * c0i);
@@ -1029,6 +1050,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (k0 + 2 < n && c == kbn) {
             Sw.colbuf[(m + 1) & 1][0][i] = a[rn0];
             Sw.colbuf[(m + 1) & 1][1][i] = a[rn1];
+            const double e_n = lane_next(a[rn0]), d1_n = lane_next(a[rn1]);  // A[k1'][k0'], A[k1'][k1'] of the next pair
+            if (i == k0 + 2) publish_pinv(a[rn0], e_n, d1_n, (m + 1) & 1);
           }
           __syncthreads();
         }
