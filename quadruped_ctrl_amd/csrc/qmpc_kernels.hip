@@ -31,6 +31,12 @@
 //   * fp64 throughout the solve (the reference hands fp32-assembled data to a
 //     double-precision qpOASES; fp64 assembly removes the fp32 rounding noise
 //     instead of adding a second, uncorrelated copy of it).
+//   * variants of the same template (own instantiations, the default kernel carries none of them):
+//     WARM  -- warm start across MPC cycles from the previous working set (qmpc_set_warm_start);
+//     ADMM  -- the reference's JCQP alternate, QpProblem::runFromDense (src/JCQP/QpProblem.cpp:178-269):
+//              same assembly and sweep with the KKT system reduced to the x block, ADMM engine;
+//     P.model = 1 -- SparseCMPC's discretisation (src/MPC_Ctrl/SparseCMPC_Math.cpp:6-28) through the same
+//              closed forms: one coefficient family and the height row of the free response change.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
