@@ -50,6 +50,9 @@ struct qmpc_ctx {
   int min_stance = 0;          // ... and lower bound (0 = unknown)
   int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
   double admm_rho = 1e-7, admm_sigma = 1e-8, admm_alpha = 1.5, admm_term = 0.1;
+  double* d_evpool = nullptr;  // largest size class: global event pool (allocated on first use)
+  int* d_evflags = nullptr;
+  int ev_nslot = 0;
   int32_t* ws = nullptr;  // warm-start buffer (device), see qmpc_set_warm_start
   int ws_shift = 1;
   double* dbg_H = nullptr;
@@ -151,6 +154,8 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_lists) hipFree(h->d_lists);
     if (h->d_counts) hipFree(h->d_counts);
     if (h->d_stage) hipFree(h->d_stage);
+    if (h->d_evpool) hipFree(h->d_evpool);
+    if (h->d_evflags) hipFree(h->d_evflags);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->order_ev) hipEventDestroy(h->order_ev);
     if (h->host_ev) hipEventDestroy(h->host_ev);
@@ -397,6 +402,18 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       if (nb <= rows[k]) { hc = k + 1; break; }
     if (hc < nclass_eff) nclass_eff = hc;
   }
+  if (nclass_eff == 4 && !c->d_evpool) {
+    // the 192-row class keeps its rank-1 events in global memory: one 192 KiB slice per workgroup in flight
+    // (256 CUs x 1 workgroup), 2048 slices so that a slice's previous tenant has long finished
+    const int nslot = c->max_batch < 2048 ? c->max_batch : 2048;
+    HIP_TRY(c, hipMalloc(&c->d_evpool, sizeof(double) * (size_t)nslot * 96 * (192 + 64)));
+    HIP_TRY(c, hipMalloc(&c->d_evflags, sizeof(int) * (size_t)nslot));
+    HIP_TRY(c, hipMemset(c->d_evflags, 0, sizeof(int) * (size_t)nslot));
+    c->ev_nslot = nslot;
+  }
+  P.evpool = c->d_evpool;
+  P.evflags = c->d_evflags;
+  P.ev_nslot = c->ev_nslot;
   const unsigned set = c->call_no & 1u;
   c->call_no++;
   int* cnt = c->d_counts + 4 * set;             // this call's counters (one per list)

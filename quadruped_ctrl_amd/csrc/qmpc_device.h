@@ -59,6 +59,10 @@ struct QmpcParams {
   // (1 = full problem, 2 = swing-eliminated) and the caller's settings (ConvexMPCLocomotion.cpp:644-648)
   int admm_mode, admm_max_iter;
   double admm_rho, admm_sigma, admm_alpha, admm_term;
+  // largest size class: event pool in global memory, ev_nslot slices of 96 x (192 + 64) doubles, one flag each
+  double* evpool;
+  int* evflags;
+  int ev_nslot;
   // warm start (nullptr = cold): [batch][QMPC_WS_STRIDE] working set of the previous cycle as global
   // constraint ids 5 * (4 step + foot) + type, -1 = empty; read slid by ws_shift horizon steps, rewritten
   // with this cycle's final working set

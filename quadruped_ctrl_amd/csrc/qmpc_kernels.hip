@@ -281,7 +281,11 @@ struct Cfg {
   static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176));
   static constexpr int NPOOL = POOL;
   static constexpr int KS = (RB == 1) ? 32 : 64;  // event-form engine: working-set slot capacity (one per lane)
-  static constexpr bool EVENT_ENGINE = (RB != 3);  // class 3 has no LDS left for events
+  static constexpr bool EVENT_ENGINE = true;
+  // class 3 has no LDS left for events: its event pool lives in global memory (one slice per workgroup in
+  // flight, L2-resident: 96 events x 2 KB), the LDS pool only serves the Schur-form fallback
+  static constexpr bool GLOBAL_EVENTS = (RB == 3);
+  static constexpr int KEV_GLOBAL = 96;
   static constexpr int MIN_WAVES = (RB == 1) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
 };
 
@@ -295,6 +299,7 @@ struct Smem {
   unsigned char kslot[64];  // foot-step k -> stance slot (0xff = swing): inverse of sidx, for the warm start
   int nst, status;
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
+  int evslot;  // class 3: this workgroup's slice of the global event pool
   // ---- phase-local storage
   union U {
     struct AW {
@@ -1115,7 +1120,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     }
   }
   if constexpr (V5) {
-    for (int k = tid; k < C::NPOOL; k += NT) Sb.Sinv[k] = 0.0;  // event rows start out zero
+    if constexpr (!C::GLOBAL_EVENTS)
+      for (int k = tid; k < C::NPOOL; k += NT) Sb.Sinv[k] = 0.0;  // event rows start out zero
   } else {
     // packed S_W^-1 behind the n(n+1)/2 doubles of the inverse (see stage 5)
     const int nh0 = n * (n + 1) / 2, cap0 = C::NH + C::NPOOL - nh0;
@@ -1309,7 +1315,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     }
   } else if constexpr (V5) {
     if (engine) {
-      constexpr int NPE = NP, KS = C::KS, EV = NPE + KS, KEV = (C::NPOOL / EV) & ~3;
+      constexpr int NPE = NP, KS = C::KS, EV = NPE + KS;
+      constexpr int KEV = C::GLOBAL_EVENTS ? C::KEV_GLOBAL : ((C::NPOOL / EV) & ~3);
+      constexpr bool GPOOL = C::GLOBAL_EVENTS;
       // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
       // 96 rows in two 64-lane blocks) read entry 0 -- harmless, those rows are never used -- and
       // do not write
@@ -1320,7 +1328,27 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         zw[q] = lane + 64 * q < NP;
         zo[q] = zw[q] ? lane + 64 * q : 0;
       }
-      double* const pool = Sb.Sinv;
+      // (global pool: this workgroup's slice, taken in the kernel prologue)
+      double* const pool = GPOOL ? P.evpool + (size_t)S.evslot * ((size_t)KEV * EV) : Sb.Sinv;
+      // rows past the last event of a group of four must read zero (the accumulation loops take four events
+      // per trip).  The LDS pool is zeroed wholesale beforehand; the global pool lazily, one group ahead
+      auto zero_group = [&](int first) __attribute__((always_inline)) {
+        if constexpr (GPOOL) {
+          if (first >= 0 && first + 4 <= KEV)
+            for (int idx = lane; idx < 4 * EV; idx += 64) pool[(size_t)first * EV + idx] = 0.0;
+        }
+      };
+      auto pool_sync = [&]() __attribute__((always_inline)) {
+        if constexpr (GPOOL) {  // event rows written by some lanes are read by others of this wave through L1 / L2
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+      };
+      if constexpr (GPOOL) {
+        zero_group(0);
+        zero_group(KEV - 4);
+        pool_sync();
+      }
       const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
       const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
       // wave-uniform predicate -> scalar branch (the operands are uniform but live in
@@ -1435,15 +1463,17 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (zw[q]) en[zo[q]] = u[q] * sg;
         if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
         // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
-        if (lane < neva) pool[lane * EV + NPE + l] = 0.0;
-        if (lane < nevd) pool[(KEV - 1 - lane) * EV + NPE + l] = 0.0;
+        for (int e = lane; e < neva; e += 64) pool[e * EV + NPE + l] = 0.0;
+        for (int e = lane; e < nevd; e += 64) pool[(KEV - 1 - e) * EV + NPE + l] = 0.0;
         if (lane == l) {
           wcid = -1;
           lam = 0.0;
         }
         if (lane == de / 5) amask &= ~(1u << (de % 5));
         nevd += 1;
+        if (GPOOL && (nevd & 3) == 0 && ((neva + 3) & ~3) + nevd + 4 <= KEV) zero_group(KEV - nevd - 4);
         __builtin_amdgcn_wave_barrier();
+        pool_sync();
         return true;
       };
       __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);  // the serial part of the workgroup: win issue arbitration
@@ -1613,6 +1643,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (lane == psl) amask |= (1u << pty);
           khw = (qslot + 1 > khw) ? qslot + 1 : khw;
           neva += 1;
+          if (GPOOL && (neva & 3) == 0 && neva + 4 + ((nevd + 3) & ~3) <= KEV) zero_group(neva);
           need_p = true;
         } else {
           // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event)
@@ -1623,6 +1654,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (!drop_slot(l, false)) break;
         }
         __builtin_amdgcn_wave_barrier();
+        pool_sync();
         if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
       }
       __builtin_amdgcn_s_setprio(0);
@@ -2101,9 +2133,28 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
     }
   }
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
+    if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
+      // take a slice of the global event pool: slot = workgroup index modulo the slice count, guarded by a flag
+      // (a workgroup whose predecessor on that slice is still running -- it would have to be ~ev_nslot / 256
+      // times slower than average -- waits for it)
+      if (threadIdx.x == 0) {
+        const int slot = (int)(blockIdx.x % (unsigned)P.ev_nslot);
+        while (atomicCAS(&P.evflags[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
+        S.evslot = slot;
+      }
+      __syncthreads();
+    }
     // projected-inverse engine first; the (rare) robot that runs out of pool is
     // solved again from scratch with the Schur-form engine, which cannot overflow
-    if (solve_one<RB, true, CMD, false, WARM>(rid, (int)threadIdx.x, S, P)) {
+    const bool again = solve_one<RB, true, CMD, false, WARM>(rid, (int)threadIdx.x, S, P);
+    if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __threadfence();
+        atomicExch(&P.evflags[S.evslot], 0);
+      }
+    }
+    if (again) {
       __syncthreads();
       // opaque thread id: without it the compiler keeps per-thread values of the
       // first run alive (spilled to scratch by EVERY workgroup) for this rare second run
