@@ -428,6 +428,8 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     const bool more = k + 1 < nclass_eff;
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;
+    if (chain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
+      HIP_TRY(c, hipMemsetAsync(c->d_evflags, 0, sizeof(int) * (size_t)c->ev_nslot, stream));
     HIP_TRY(c, qmpc_launch(chain[k], &P, batch, stream));
   }
   return QMPC_OK;

@@ -2139,7 +2139,9 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
       // times slower than average -- waits for it)
       if (threadIdx.x == 0) {
         const int slot = (int)(blockIdx.x % (unsigned)P.ev_nslot);
-        while (atomicCAS(&P.evflags[slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
+        // (bounded: a flag left behind by an aborted launch must not hang this one; the host clears the flags
+        //  before every launch of this class anyway)
+        for (int spin = 0; spin < (1 << 16) && atomicCAS(&P.evflags[slot], 0, 1) != 0; ++spin) __builtin_amdgcn_s_sleep(8);
         S.evslot = slot;
       }
       __syncthreads();
