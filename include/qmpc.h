@@ -67,6 +67,11 @@ extern "C" {
                                 slower Schur-form engine because the fast engine's
                                 working-set pool was exhausted */
 #define QMPC_ST_NONFINITE 32 /* the result contains NaN / Inf (non-finite input) */
+#define QMPC_ST_COMPACTED 64 /* informational, NOT an error: the fast engine ran out of pool with
+                                constraints that had entered and left the working set again, and
+                                rebuilt its records from the current working set (no second solve) */
+#define QMPC_ST_SPILLED 128  /* informational, NOT an error: the fast engine's on-chip pool was full and the
+                                robot continued on a slice of the handle's overflow pool in global memory */
 #define QMPC_ST_ERROR_MASK (15 | 32)
 
 typedef struct qmpc_ctx* qmpc_handle;

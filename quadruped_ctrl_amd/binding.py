@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 QMPC_OK = 0
 ABI_VERSION = 11              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
+ST_COMPACTED, ST_SPILLED = 64, 128
 ST_NONFINITE = 32
 ST_ERROR_MASK = 15 | 32
 EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",

@@ -15,8 +15,51 @@
 #include "../../include/qmpc.h"
 #include "qmpc_device.h"
 
-extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
-extern "C" hipError_t qmpc_prepare(void);
+// per-class entry points of qmpc_kernels.hip (one translation unit per size class)
+#define QMPC_DECLARE_CLASS(RB)                                                                  \
+  extern "C" size_t qmpc_c##RB##_smem(void);                                                    \
+  extern "C" hipError_t qmpc_c##RB##_prepare(void);                                             \
+  extern "C" int qmpc_c##RB##_resident(void);                                                   \
+  extern "C" hipError_t qmpc_c##RB##_launch(const QmpcParams* P, int grid, hipStream_t stream);
+QMPC_DECLARE_CLASS(1)
+QMPC_DECLARE_CLASS(2)
+QMPC_DECLARE_CLASS(3)
+QMPC_DECLARE_CLASS(4)
+
+extern "C" size_t qmpc_smem_bytes(int rb) {
+  switch (rb) {
+    case 1: return qmpc_c1_smem();
+    case 2: return qmpc_c2_smem();
+    case 3: return qmpc_c3_smem();
+    case 4: return qmpc_c4_smem();
+  }
+  return 0;
+}
+extern "C" int qmpc_resident_blocks(int rb) {
+  switch (rb) {
+    case 1: return qmpc_c1_resident();
+    case 2: return qmpc_c2_resident();
+    case 3: return qmpc_c3_resident();
+    case 4: return qmpc_c4_resident();
+  }
+  return 0;
+}
+static hipError_t qmpc_prepare(void) {
+  hipError_t e;
+  if ((e = qmpc_c1_prepare()) != hipSuccess) return e;
+  if ((e = qmpc_c4_prepare()) != hipSuccess) return e;
+  if ((e = qmpc_c2_prepare()) != hipSuccess) return e;
+  return qmpc_c3_prepare();
+}
+static hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
+  switch (rb) {
+    case 1: return qmpc_c1_launch(P, grid, stream);
+    case 2: return qmpc_c2_launch(P, grid, stream);
+    case 3: return qmpc_c3_launch(P, grid, stream);
+    case 4: return qmpc_c4_launch(P, grid, stream);
+  }
+  return hipErrorInvalidValue;
+}
 extern "C" hipError_t qmpc_launch_pack(const qmpc_command* c, const qmpc_record* rec, int batch, int horizon, float dt_mpc,
                                        hipStream_t stream);
 extern "C" hipError_t qmpc_launch_f2b(const float* r_body, const float* grf, float* f_ff, int batch, hipStream_t stream);
@@ -44,13 +87,15 @@ struct qmpc_ctx {
   float leg_geom[4] = {0.062f, 0.209f, 0.195f, 0.004f};  // MiniCheetah.h:31-37 (abad, hip, knee, knee Y offset)
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
   int* d_lists = nullptr;      // [3][max_batch] robot ids handed to classes 4, 2 and 3
-  int* d_counts = nullptr;     // [2 sets][4]: list lengths of classes 4, 2, 3 (+pad), ping-ponged between calls
+  int* d_counts = nullptr;     // [2 sets][8]: list lengths of classes 4, 2, 3 (+pad), their queue heads, overflow-slice counter; ping-ponged between calls
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
   int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
   double admm_rho = 1e-7, admm_sigma = 1e-8, admm_alpha = 1.5, admm_term = 0.1;
   double* d_evpool = nullptr;  // largest size class: global event pool (allocated on first use)
+  double* d_ovpool = nullptr;  // the other classes: overflow event pool, ov_nslice slices handed out per launch chain
+  int ov_nslice = 0;
   int* d_evflags = nullptr;
   int ev_nslot = 0;
   int32_t* ws = nullptr;  // warm-start buffer (device), see qmpc_set_warm_start
@@ -135,8 +180,14 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   const size_t H = (size_t)max_horizon;
   hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
   if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 3 * (size_t)max_batch);
-  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 8);
-  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 8);
+  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 16);
+  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 16);
+  if (e == hipSuccess) {
+    // a robot whose on-chip event pool fills up continues here; more than ov_nslice of them in one launch chain
+    // fall back to the Schur-form engine
+    c->ov_nslice = max_batch < 256 ? max_batch : 256;
+    e = hipMalloc(&c->d_ovpool, sizeof(double) * (size_t)c->ov_nslice * QMPC_OV_SLICE);
+  }
   if (e == hipSuccess) e = qmpc_prepare();
   if (e != hipSuccess) {
     qmpc_destroy(c);
@@ -155,6 +206,7 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_counts) hipFree(h->d_counts);
     if (h->d_stage) hipFree(h->d_stage);
     if (h->d_evpool) hipFree(h->d_evpool);
+    if (h->d_ovpool) hipFree(h->d_ovpool);
     if (h->d_evflags) hipFree(h->d_evflags);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->order_ev) hipEventDestroy(h->order_ev);
@@ -383,7 +435,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_clk = c->dbg_clk;
 
   // size classes by padded rows: 64 (kernel class 1), 96 (class 4), 128 (class 2), 192 (class 3);
-  // n_r = 3 * stance foot-steps.  Every class is launched over the whole batch; a robot that
+  // n_r = 3 * stance foot-steps.  The first class is launched over the whole batch; a robot that
   // does not fit appends itself to the list of the next one.
   static const int chain[4] = {1, 4, 2, 3};
   static const int rows[4] = {64, 96, 128, 192};
@@ -411,26 +463,37 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     HIP_TRY(c, hipMemset(c->d_evflags, 0, sizeof(int) * (size_t)nslot));
     c->ev_nslot = nslot;
   }
+  P.ovpool = c->d_ovpool;
+  P.ov_nslice = c->ov_nslice;
   P.evpool = c->d_evpool;
   P.evflags = c->d_evflags;
   P.ev_nslot = c->ev_nslot;
   const unsigned set = c->call_no & 1u;
   c->call_no++;
-  int* cnt = c->d_counts + 4 * set;             // this call's counters (one per list)
-  int* cnt_next = c->d_counts + 4 * (set ^ 1u); // cleared by this call's first kernel
+  int* cnt = c->d_counts + 8 * set;             // this call's counters (one per list)
+  int* cnt_next = c->d_counts + 8 * (set ^ 1u); // cleared by this call's first kernel
+  P.ov_count = cnt + 7;                         // slices of the overflow pool handed out in this call
   // ... and with a lower bound the classes that are too small for every robot are skipped
   int k0 = 0;
   while (k0 + 1 < nclass_eff && 3 * (full_problem ? 4 * h : c->min_stance) > rows[k0]) ++k0;
   for (int k = k0; k < nclass_eff; ++k) {
     P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
     P.count = k > k0 ? cnt + (k - 1) : nullptr;
+    P.qhead = k > k0 ? cnt + 4 + (k - 1) : nullptr;
     P.clear_counts = k > k0 ? nullptr : cnt_next;
     const bool more = k + 1 < nclass_eff;
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;
     if (chain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
       HIP_TRY(c, hipMemsetAsync(c->d_evflags, 0, sizeof(int) * (size_t)c->ev_nslot, stream));
-    HIP_TRY(c, qmpc_launch(chain[k], &P, batch, stream));
+    // the first class of the chain: one workgroup per robot; the later ones: one per resident slot, the list
+    // is consumed as a queue (no workgroup is dispatched only to find its list entry missing)
+    int grid = batch;
+    if (k > k0) {
+      const int res = qmpc_resident_blocks(chain[k]);
+      if (res > 0 && res < grid) grid = res;
+    }
+    HIP_TRY(c, qmpc_launch(chain[k], &P, grid, stream));
   }
   return QMPC_OK;
 }

@@ -12,9 +12,14 @@
 #define QMPC_DEV_ST_WS_FULL 8
 #define QMPC_DEV_ST_FALLBACK 16
 #define QMPC_DEV_ST_NONFINITE 32
+#define QMPC_DEV_ST_COMPACTED 64
+#define QMPC_DEV_ST_SPILLED 128
 
 // warm start: working-set slots kept per robot between MPC cycles (QMPC_WS_SLOTS of qmpc.h)
 #define QMPC_WS_STRIDE 64
+// one slice of a global event pool: 96 events x (192 rows + 64 slots) doubles (the largest class's record; the
+// smaller classes use the front of it)
+#define QMPC_OV_SLICE (96 * 256)
 
 // leading dimension of the debug dump (largest padded size, 3 * 64)
 #define QMPC_DBG_LD 192
@@ -63,6 +68,11 @@ struct QmpcParams {
   double* evpool;
   int* evflags;
   int ev_nslot;
+  // classes 1, 4, 2: overflow pool in global memory for the robot whose LDS event pool is full: ov_nslice slices of
+  // QMPC_OV_SLICE doubles, handed out by the counter *ov_count (one per robot and launch chain; nullptr = none)
+  double* ovpool;
+  int* ov_count;
+  int ov_nslice;
   // warm start (nullptr = cold): [batch][QMPC_WS_STRIDE] working set of the previous cycle as global
   // constraint ids 5 * (4 step + foot) + type, -1 = empty; read slid by ws_shift horizon steps, rewritten
   // with this cycle's final working set
@@ -71,7 +81,8 @@ struct QmpcParams {
   // work lists: robots handed from one size class to the next
   const int* list;   // nullptr: robot = blockIdx.x
   int* count;        // entries in `list`
-  int* clear_counts; // class-1 kernel: the two counters of the NEXT call's set, zeroed here
+  int* qhead;        // queue head of `list`: entries past the grid size are handed out through it
+  int* clear_counts; // first kernel of the chain: the counters and queue heads of the NEXT call's set (8 ints), zeroed here
   int* next_list;    // nullptr: no larger class available
   int* next_count;
   // command mode (qmpc_solve_commands; c_position == nullptr: off): the record is built in

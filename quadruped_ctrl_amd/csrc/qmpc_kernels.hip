@@ -46,6 +46,7 @@
 #include "qmpc_cmd.h"
 
 namespace {
+typedef __attribute__((address_space(1))) double GlobalF64;  // a double known to live in global memory (global_load, not flat_load)
 
 constexpr int WAVE = 64;
 #ifndef QMPC_ENGINE_PRIO
@@ -286,7 +287,7 @@ struct Cfg {
   // flight, L2-resident: 96 events x 2 KB), the LDS pool only serves the Schur-form fallback
   static constexpr bool GLOBAL_EVENTS = (RB == 3);
   static constexpr int KEV_GLOBAL = 96;
-  static constexpr int MIN_WAVES = (RB == 1) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
+  static constexpr int MIN_WAVES = (RB == 1 || RB == 4) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
 };
 
 template <int RB>
@@ -300,6 +301,7 @@ struct Smem {
   int nst, status;
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   int evslot;  // class 3: this workgroup's slice of the global event pool
+  int qnext;   // next entry of the work list (classes launched after the first)
   // ---- phase-local storage
   union U {
     struct AW {
@@ -1316,8 +1318,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   } else if constexpr (V5) {
     if (engine) {
       constexpr int NPE = NP, KS = C::KS, EV = NPE + KS;
-      constexpr int KEV = C::GLOBAL_EVENTS ? C::KEV_GLOBAL : ((C::NPOOL / EV) & ~3);
-      constexpr bool GPOOL = C::GLOBAL_EVENTS;
+      // event capacity: LDS pool of this class / a slice of a global pool (class 3: its only pool; the other
+      // classes: where a robot continues when its LDS pool is full)
+      constexpr int KEV_L = (C::NPOOL / EV) & ~3, KEV_G = C::KEV_GLOBAL;
       // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
       // 96 rows in two 64-lane blocks) read entry 0 -- harmless, those rows are never used -- and
       // do not write
@@ -1327,27 +1330,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       for (int q = 0; q < RE; ++q) {
         zw[q] = lane + 64 * q < NP;
         zo[q] = zw[q] ? lane + 64 * q : 0;
-      }
-      // (global pool: this workgroup's slice, taken in the kernel prologue)
-      double* const pool = GPOOL ? P.evpool + (size_t)S.evslot * ((size_t)KEV * EV) : Sb.Sinv;
-      // rows past the last event of a group of four must read zero (the accumulation loops take four events
-      // per trip).  The LDS pool is zeroed wholesale beforehand; the global pool lazily, one group ahead
-      auto zero_group = [&](int first) __attribute__((always_inline)) {
-        if constexpr (GPOOL) {
-          if (first >= 0 && first + 4 <= KEV)
-            for (int idx = lane; idx < 4 * EV; idx += 64) pool[(size_t)first * EV + idx] = 0.0;
-        }
-      };
-      auto pool_sync = [&]() __attribute__((always_inline)) {
-        if constexpr (GPOOL) {  // event rows written by some lanes are read by others of this wave through L1 / L2
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-      };
-      if constexpr (GPOOL) {
-        zero_group(0);
-        zero_group(KEV - 4);
-        pool_sync();
       }
       const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
       const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
@@ -1359,7 +1341,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       int wcid = -1;       // working-slot lane: constraint id in slot `lane`, -1 = free
       double lam = 0.0;    // ... and its multiplier
       int khw = 0, status = 0, neva = 0, nevd = 0;
-      bool need_p = true;
+      bool need_p0 = true;  // (carried between the two runs; each run works on its own copy)
+      unsigned long long rbm = 0ull;  // compaction in progress: working-set slots whose add event is still to be rebuilt
+      bool spill = false;             // the LDS pool is full: continue on a slice of the overflow pool
       // ---- warm start (qmpc_set_warm_start): the previous cycle's working set, slid by `ws_shift`
       // horizon steps and mapped onto this cycle's stance slots, one candidate per lane.  The
       // candidates are ADDED FIRST, without search or ratio test (a full step onto each, whatever the
@@ -1412,250 +1396,366 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         y = __builtin_fma(0.5 * y, e, y);
         return y;
       };
-      // Remove working-set slot l: one drop event.  u = N*_l (index-major lanes), sc = S^-1[:, l]
-      // (slot lanes), gamma = S^-1[l][l].  With `repair` (warm start) the iterate also moves to the
-      // minimiser of the problem WITHOUT that constraint: x -= (lam_l / gamma) u, lam -= (lam_l / gamma) sc.
-      // Returns false when the projected inverse has lost definiteness numerically (retry is set).
-      auto drop_slot = [&](int l, bool repair) __attribute__((always_inline)) {
-        double u[RE], sc = 0.0;
-#pragma unroll
-        for (int q = 0; q < RE; ++q) u[q] = 0.0;
-        auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
-          constexpr int DIR = decltype(dirc)::value;
-#pragma unroll 1
-          for (int t0 = 0; t0 < cnt; t0 += 4) {
-            const double* ev = pool + (base + DIR * t0) * EV;
-            double gll[4], zl[4][RE], gw[4];
-#pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
-              const double* eu = ev + DIR * u4 * EV;
-              gll[u4] = eu[NPE + l];
-#pragma unroll
-              for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
-              gw[u4] = eu[gl_off];
-            }
-#pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
-#pragma unroll
-              for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
-              sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
-            }
+      // ---- the iteration, on the LDS pool (gpc = false) or on a slice of a global pool (true).  Everything it
+      // carries from one trip to the next lives outside, so that a robot can leave the first and continue in
+      // the second
+      auto run = [&](auto gpc, GlobalF64* const gpool) __attribute__((always_inline)) {
+        constexpr bool GPOOL = decltype(gpc)::value;
+        constexpr int KEV = GPOOL ? KEV_G : KEV_L;
+        // (locals, not captures: a flag that nested lambdas reach through two closures ends up in scratch)
+        bool need_p = need_p0, retry = false;
+        const auto pool = [&]() __attribute__((always_inline)) {
+          if constexpr (GPOOL) return gpool; else return (double*)Sb.Sinv;
+        }();
+        // rows past the last event of a group of four must read zero (the accumulation loops take four events
+        // per trip).  The LDS pool is zeroed wholesale beforehand; the global pool lazily, one group ahead
+        auto zero_group = [&](int first) __attribute__((always_inline)) {
+          if constexpr (GPOOL) {
+            if (first >= 0 && first + 4 <= KEV)
+              for (int idx = lane; idx < 4 * EV; idx += 64) pool[(size_t)first * EV + idx] = 0.0;
           }
         };
-        dacc(std::integral_constant<int, 1>{}, 0, neva);
-        if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
-        const double gamma = readlane_f64(sc, l);
-        if (uni(!(gamma > 0.0))) {
-          retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
-          return false;
-        }
-        if (repair) {
-          const double coef = readlane_f64(lam, l) * fast_rcp(gamma);
-#pragma unroll
-          for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(-coef, u[q], xv[q]);
-          lam = __builtin_fma(-coef, sc, lam);
-        }
-        const double sg = rsqrt_full(gamma);
-        const int de = __builtin_amdgcn_readlane(wcid, l);
-        double* en = pool + (KEV - 1 - nevd) * EV;
-#pragma unroll
-        for (int q = 0; q < RE; ++q)
-          if (zw[q]) en[zo[q]] = u[q] * sg;
-        if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
-        // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
-        for (int e = lane; e < neva; e += 64) pool[e * EV + NPE + l] = 0.0;
-        for (int e = lane; e < nevd; e += 64) pool[(KEV - 1 - e) * EV + NPE + l] = 0.0;
-        if (lane == l) {
-          wcid = -1;
-          lam = 0.0;
-        }
-        if (lane == de / 5) amask &= ~(1u << (de % 5));
-        nevd += 1;
-        if (GPOOL && (nevd & 3) == 0 && ((neva + 3) & ~3) + nevd + 4 <= KEV) zero_group(KEV - nevd - 4);
-        __builtin_amdgcn_wave_barrier();
-        pool_sync();
-        return true;
-      };
-      __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);  // the serial part of the workgroup: win issue arbitration
+        auto pool_sync = [&]() __attribute__((always_inline)) {
+          if constexpr (GPOOL) {  // event rows written by some lanes are read by others of this wave through L1 / L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+        };
+        // Remove working-set slot l: one drop event.  u = N*_l (index-major lanes), sc = S^-1[:, l]
+        // (slot lanes), gamma = S^-1[l][l].  With `repair` (warm start) the iterate also moves to the
+        // minimiser of the problem WITHOUT that constraint: x -= (lam_l / gamma) u, lam -= (lam_l / gamma) sc.
+        // Returns false when the projected inverse has lost definiteness numerically (retry is set).
+        auto drop_slot = [&](int l, bool repair) __attribute__((always_inline)) {
+          double u[RE], sc = 0.0;
+  #pragma unroll
+          for (int q = 0; q < RE; ++q) u[q] = 0.0;
+          auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
+            constexpr int DIR = decltype(dirc)::value;
+  #pragma unroll 1
+            for (int t0 = 0; t0 < cnt; t0 += 4) {
+              const auto ev = pool + (base + DIR * t0) * EV;
+              double gll[4], zl[4][RE], gw[4];
+  #pragma unroll
+              for (int u4 = 0; u4 < 4; ++u4) {
+                const auto eu = ev + DIR * u4 * EV;
+                gll[u4] = eu[NPE + l];
+  #pragma unroll
+                for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
+                gw[u4] = eu[gl_off];
+              }
+  #pragma unroll
+              for (int u4 = 0; u4 < 4; ++u4) {
+  #pragma unroll
+                for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
+                sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
+              }
+            }
+          };
+          dacc(std::integral_constant<int, 1>{}, 0, neva);
+          if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
+          const double gamma = readlane_f64(sc, l);
+          if (uni(!(gamma > 0.0))) {
+            retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
+            return false;
+          }
+          if (repair) {
+            const double coef = readlane_f64(lam, l) * fast_rcp(gamma);
+  #pragma unroll
+            for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(-coef, u[q], xv[q]);
+            lam = __builtin_fma(-coef, sc, lam);
+          }
+          const double sg = rsqrt_full(gamma);
+          const int de = __builtin_amdgcn_readlane(wcid, l);
+          const auto en = pool + (KEV - 1 - nevd) * EV;
+  #pragma unroll
+          for (int q = 0; q < RE; ++q)
+            if (zw[q]) en[zo[q]] = u[q] * sg;
+          if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
+          // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
+          for (int e = lane; e < neva; e += 64) pool[e * EV + NPE + l] = 0.0;
+          for (int e = lane; e < nevd; e += 64) pool[(KEV - 1 - e) * EV + NPE + l] = 0.0;
+          if (lane == l) {
+            wcid = -1;
+            lam = 0.0;
+          }
+          if (lane == de / 5) amask &= ~(1u << (de % 5));
+          nevd += 1;
+          if (GPOOL && (nevd & 3) == 0 && ((neva + 3) & ~3) + nevd + 4 <= KEV) zero_group(KEV - nevd - 4);
+          __builtin_amdgcn_wave_barrier();
+          pool_sync();
+          return true;
+        };
 
-      while (true) {
-        // loop-carried counters are wave-uniform: keep them in SGPRs
-        iters = __builtin_amdgcn_readfirstlane(iters);
-        khw = __builtin_amdgcn_readfirstlane(khw);
-        neva = __builtin_amdgcn_readfirstlane(neva);
-        nevd = __builtin_amdgcn_readfirstlane(nevd);
-        status = __builtin_amdgcn_readfirstlane(status);
-        p_e = __builtin_amdgcn_readfirstlane(p_e);
-        psl = __builtin_amdgcn_readfirstlane(psl);
-        pty = __builtin_amdgcn_readfirstlane(pty);
-        pj1 = __builtin_amdgcn_readfirstlane(pj1);
-        pj2 = __builtin_amdgcn_readfirstlane(pj2);
-        if (WARM && uni(need_p) && cmask != 0ull) {
-          // ---- warm start: next candidate of the previous working set, forced
-          const int cl = __ffsll((long long)cmask) - 1;
-          cmask &= cmask - 1ull;
-          p_e = __builtin_amdgcn_readlane(cand, cl);
-          psl = p_e / 5;
-          pty = p_e - 5 * psl;
-          con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
-          p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
-          lp = 0.0;
-          need_p = false;
-          forced = true;
-        } else if (WARM && uni(need_p) && fixneg) {
-          // ---- warm start, second phase: a candidate whose multiplier is negative does not belong to
-          // the working set -- remove it (one drop event) and move to the minimiser without it
-          const unsigned long long nm = __ballot(wcid >= 0 && lam < 0.0);
-          if (nm == 0ull) {
-            fixneg = false;
+        while (true) {
+          // loop-carried counters are wave-uniform: keep them in SGPRs
+          iters = __builtin_amdgcn_readfirstlane(iters);
+          khw = __builtin_amdgcn_readfirstlane(khw);
+          neva = __builtin_amdgcn_readfirstlane(neva);
+          nevd = __builtin_amdgcn_readfirstlane(nevd);
+          status = __builtin_amdgcn_readfirstlane(status);
+          p_e = __builtin_amdgcn_readfirstlane(p_e);
+          psl = __builtin_amdgcn_readfirstlane(psl);
+          pty = __builtin_amdgcn_readfirstlane(pty);
+          pj1 = __builtin_amdgcn_readfirstlane(pj1);
+          pj2 = __builtin_amdgcn_readfirstlane(pj2);
+          // ---- room for one more event of either kind?  Checked here, between iterations, where the state is
+          // consistent.  LDS pool: no -> leave the loop, the events move to this robot's slice of the overflow pool
+          // in global memory and the iteration continues there (`spill`).  Global pool: no -> compaction.  Every
+          // working-set change costs an event; a constraint that entered and left again holds two records that
+          // cancel.  With drop events in the pool: forget all records and rebuild the projected inverse from H^-1
+          // with one add event per constraint that is in the working set NOW (x, the multipliers and the pending
+          // constraint are untouched: the operators are the same, only their representation is shorter).
+          if (rbm == 0ull && ((neva + 4) & ~3) + ((nevd + 4) & ~3) > KEV) {
+            if constexpr (!GPOOL) {
+              spill = true;
+              break;
+            } else {
+              if (nevd == 0) {
+                retry = true;  // the working set alone fills the pool: the robot is re-run with the Schur-form engine
+                break;
+              }
+              rbm = __ballot(lane < KS && wcid >= 0);
+              status |= QMPC_DEV_ST_COMPACTED;  // informational
+              neva = 0;
+              nevd = 0;
+              zero_group(0);
+              zero_group(KEV - 4);
+              __builtin_amdgcn_wave_barrier();
+              pool_sync();
+            }
+          }
+          const bool rebuild = GPOOL && rbm != 0ull;
+          int rl = 0;
+          if (rebuild) {
+            rl = __ffsll((long long)rbm) - 1;
+            rbm &= rbm - 1ull;
+            con_coefs(__builtin_amdgcn_readlane(wcid, rl), mi, pj1, pj2, pa1, pa2);
+          } else {
+          if (WARM && uni(need_p) && cmask != 0ull) {
+            // ---- warm start: next candidate of the previous working set, forced
+            const int cl = __ffsll((long long)cmask) - 1;
+            cmask &= cmask - 1ull;
+            p_e = __builtin_amdgcn_readlane(cand, cl);
+            psl = p_e / 5;
+            pty = p_e - 5 * psl;
+            con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+            p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
+            lp = 0.0;
+            need_p = false;
+            forced = true;
+          } else if (WARM && uni(need_p) && fixneg) {
+            // ---- warm start, second phase: a candidate whose multiplier is negative does not belong to
+            // the working set -- remove it (one drop event) and move to the minimiser without it
+            const unsigned long long nm = __ballot(wcid >= 0 && lam < 0.0);
+            if (nm == 0ull) {
+              fixneg = false;
+              continue;
+            }
+            if (iters >= max_iter) {
+              retry = true;  // the guess cannot be repaired within the iteration limit: start over, cold, with the other engine
+              break;
+            }
+            const int l = __ffsll((long long)nm) - 1;
+            if (!drop_slot(l, true)) break;
+            iters += 1;
             continue;
           }
-          if (((neva + 3) & ~3) + ((nevd + 4) & ~3) > KEV || iters >= max_iter) {
-            retry = true;  // no room to repair the guess: start over, cold, with the other engine
+          if (uni(need_p)) {
+            // ---- most violated constraint outside the working set (normalised), or done
+            unsigned key = 0;
+            const int j0 = 3 * (lane < nst ? lane : 0);
+            const double x0 = gather(xv, j0), x1 = gather(xv, j0 + 1), x2 = gather(xv, j0 + 2);
+            if (lane < nst) {
+              const double fx = mi * x0, fy = mi * x1;
+              double vmin = 0.0;
+              int tmin = -1;
+              const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx - x2};
+  #pragma unroll
+              for (int ty = 0; ty < 5; ++ty) {
+                const bool cand = !((amask >> ty) & 1u) && sv[ty] < vmin;
+                vmin = cand ? sv[ty] : vmin;
+                tmin = cand ? ty : tmin;
+              }
+              if (vmin < -tol) key = (__float_as_uint((float)(-vmin)) & ~0x1FFu) | (unsigned)(5 * lane + tmin);
+            }
+            const unsigned best = wave_max_u32(key);
+            if (best == 0u) break;
+            if (iters >= max_iter) {
+              status |= QMPC_DEV_ST_MAXITER;
+              break;
+            }
+            p_e = (int)(best & 0x1FFu);
+            psl = p_e / 5;
+            pty = p_e - 5 * psl;
+            con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+            p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
+            lp = 0.0;
+            need_p = false;
+            forced = false;
+          }
+          }  // (!rebuild)
+          if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
+          // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
+          double z[RE];
+  #pragma unroll
+          for (int q = 0; q < RE; ++q) {
+            const int row = lane + 64 * q;
+            z[q] = (row < n) ? __builtin_fma(pa2, Hcol(q, pj2), pa1 * Hcol(q, pj1)) : 0.0;
+          }
+          double rw = 0.0;
+          // four events per trip (rows past the last event are zero): y = z~^T c_p,
+          // z -= +-y z~ , r += y g~
+          auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
+            constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
+  #pragma unroll 1
+            for (int t0 = 0; t0 < cnt; t0 += 4) {
+              const auto ev = pool + (base + DIR * t0) * EV;
+              double ya[4], yb[4], zl[4][RE], gl[4];
+  #pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const auto eu = ev + DIR * u * EV;
+                ya[u] = eu[pj1];
+                yb[u] = eu[pj2];
+  #pragma unroll
+                for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
+                gl[u] = eu[gl_off];
+              }
+  #pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
+  #pragma unroll
+                for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
+                rw = __builtin_fma(y, gl[u], rw);
+              }
+            }
+          };
+          accum(std::integral_constant<int, 1>{}, 0, neva);
+          if (nevd > 0) accum(std::integral_constant<int, -1>{}, KEV - 1, nevd);
+          const double delta = __builtin_fma(pa2, bcast(z, pj2), pa1 * bcast(z, pj1));
+          const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
+          const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
+          if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
+          const bool dep = uni(!(delta > 1e-11 * cn));
+          if (rebuild) {
+            // the add event of slot rl, exactly as in the full step below (r is zero for the slots not rebuilt yet)
+            if (uni(!(delta > 0.0))) {
+              retry = true;
+              break;
+            }
+            const double s = rsqrt_full(delta);
+            const auto en = pool + neva * EV;
+  #pragma unroll
+            for (int q = 0; q < RE; ++q)
+              if (zw[q]) en[zo[q]] = z[q] * s;
+            if (lane < KS) en[NPE + lane] = (lane == rl) ? s : ((wcid >= 0) ? -rw * s : 0.0);
+            neva += 1;
+            if (GPOOL && (neva & 3) == 0 && neva + 4 <= KEV) zero_group(neva);
+            if (rbm == 0ull && !need_p) con_coefs(p_e, mi, pj1, pj2, pa1, pa2);  // the pending constraint's coefficients again
+            __builtin_amdgcn_wave_barrier();
+            pool_sync();
+            continue;
+          }
+          if (WARM && forced && dep) {  // a candidate that depends on the ones already added: skip it
+            need_p = true;
+            continue;
+          }
+          const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
+          double ratio = __builtin_inf();
+          if (!(WARM && forced) && wcid >= 0 && rw > 0.0) {
+            const double qv = lam * fast_rcp(rw);
+            ratio = qv > 0.0 ? qv : 0.0;
+          }
+          double t1 = __builtin_inf();
+          int l = -1;
+          if (khw > 0 && !(WARM && forced)) {
+            t1 = wave_min_pos_f64(ratio);
+            if (uni(t1 < __builtin_inf())) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
+          }
+          const double t = (t2 <= t1) ? t2 : t1;
+          if (uni(!(t < __builtin_inf()))) {
+            status |= QMPC_DEV_ST_INFEASIBLE;
             break;
           }
-          const int l = __ffsll((long long)nm) - 1;
-          if (!drop_slot(l, true)) break;
+          if (!dep) {
+  #pragma unroll
+            for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
+          }
+          lam -= t * rw;
+          lp += t;
           iters += 1;
-          continue;
-        }
-        if (uni(need_p)) {
-          // ---- most violated constraint outside the working set (normalised), or done
-          unsigned key = 0;
-          const int j0 = 3 * (lane < nst ? lane : 0);
-          const double x0 = gather(xv, j0), x1 = gather(xv, j0 + 1), x2 = gather(xv, j0 + 2);
-          if (lane < nst) {
-            const double fx = mi * x0, fy = mi * x1;
-            double vmin = 0.0;
-            int tmin = -1;
-            const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx - x2};
-#pragma unroll
-            for (int ty = 0; ty < 5; ++ty) {
-              const bool cand = !((amask >> ty) & 1u) && sv[ty] < vmin;
-              vmin = cand ? sv[ty] : vmin;
-              tmin = cand ? ty : tmin;
+          if (uni(t2 <= t1)) {
+            // ---- full step: p joins the working set in the first free slot (an add event)
+            const unsigned long long fm = __ballot(lane < KS && wcid < 0);
+            const int qslot = fm ? __ffsll((long long)fm) - 1 : -1;
+            if (qslot < 0) {
+              retry = true;  // out of working-set slots: the robot is re-run with the Schur-form engine
+              break;
             }
-            if (vmin < -tol) key = (__float_as_uint((float)(-vmin)) & ~0x1FFu) | (unsigned)(5 * lane + tmin);
-          }
-          const unsigned best = wave_max_u32(key);
-          if (best == 0u) break;
-          if (iters >= max_iter) {
-            status |= QMPC_DEV_ST_MAXITER;
-            break;
-          }
-          p_e = (int)(best & 0x1FFu);
-          psl = p_e / 5;
-          pty = p_e - 5 * psl;
-          con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
-          p_rhs = (pty == 4) ? -readlane_f64(fmx, psl) : 0.0;
-          lp = 0.0;
-          need_p = false;
-          forced = false;
-        }
-        if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
-        // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
-        double z[RE];
-#pragma unroll
-        for (int q = 0; q < RE; ++q) {
-          const int row = lane + 64 * q;
-          z[q] = (row < n) ? __builtin_fma(pa2, Hcol(q, pj2), pa1 * Hcol(q, pj1)) : 0.0;
-        }
-        double rw = 0.0;
-        // four events per trip (rows past the last event are zero): y = z~^T c_p,
-        // z -= +-y z~ , r += y g~
-        auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
-          constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
-#pragma unroll 1
-          for (int t0 = 0; t0 < cnt; t0 += 4) {
-            const double* ev = pool + (base + DIR * t0) * EV;
-            double ya[4], yb[4], zl[4][RE], gl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double* eu = ev + DIR * u * EV;
-              ya[u] = eu[pj1];
-              yb[u] = eu[pj2];
-#pragma unroll
-              for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
-              gl[u] = eu[gl_off];
+            const double s = rsqrt_full(delta);
+            const auto en = pool + neva * EV;
+  #pragma unroll
+            for (int q = 0; q < RE; ++q)
+              if (zw[q]) en[zo[q]] = z[q] * s;
+            if (lane < KS) en[NPE + lane] = (lane == qslot) ? s : ((wcid >= 0) ? -rw * s : 0.0);
+            if (lane == qslot) {
+              wcid = p_e;
+              lam = lp;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
-#pragma unroll
-              for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
-              rw = __builtin_fma(y, gl[u], rw);
-            }
+            if (lane == psl) amask |= (1u << pty);
+            khw = (qslot + 1 > khw) ? qslot + 1 : khw;
+            neva += 1;
+            if (GPOOL && (neva & 3) == 0 && neva + 4 + ((nevd + 3) & ~3) <= KEV) zero_group(neva);
+            need_p = true;
+          } else {
+            // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event)
+            if (!drop_slot(l, false)) break;
           }
-        };
-        accum(std::integral_constant<int, 1>{}, 0, neva);
-        if (nevd > 0) accum(std::integral_constant<int, -1>{}, KEV - 1, nevd);
-        const double delta = __builtin_fma(pa2, bcast(z, pj2), pa1 * bcast(z, pj1));
-        const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
-        const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
-        if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
-        const bool dep = uni(!(delta > 1e-11 * cn));
-        if (WARM && forced && dep) {  // a candidate that depends on the ones already added: skip it
-          need_p = true;
-          continue;
+          __builtin_amdgcn_wave_barrier();
+          pool_sync();
+          if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
         }
-        const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
-        double ratio = __builtin_inf();
-        if (!(WARM && forced) && wcid >= 0 && rw > 0.0) {
-          const double qv = lam * fast_rcp(rw);
-          ratio = qv > 0.0 ? qv : 0.0;
+        need_p0 = need_p;
+        return retry;
+      };
+      __builtin_amdgcn_s_setprio(QMPC_ENGINE_PRIO);  // the serial part of the workgroup: win issue arbitration
+      if constexpr (C::GLOBAL_EVENTS) {
+        // (this workgroup's slice of the class's pool, taken in the kernel prologue)
+        GlobalF64* const gpool = (GlobalF64*)P.evpool + (size_t)S.evslot * ((size_t)KEV_G * EV);
+        for (int idx = lane; idx < 4 * EV; idx += 64) {
+          gpool[idx] = 0.0;
+          gpool[(size_t)(KEV_G - 4) * EV + idx] = 0.0;
         }
-        double t1 = __builtin_inf();
-        int l = -1;
-        if (khw > 0 && !(WARM && forced)) {
-          t1 = wave_min_pos_f64(ratio);
-          if (uni(t1 < __builtin_inf())) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
-        }
-        const double t = (t2 <= t1) ? t2 : t1;
-        if (uni(!(t < __builtin_inf()))) {
-          status |= QMPC_DEV_ST_INFEASIBLE;
-          break;
-        }
-        if (!dep) {
-#pragma unroll
-          for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
-        }
-        lam -= t * rw;
-        lp += t;
-        iters += 1;
-        if (uni(t2 <= t1)) {
-          // ---- full step: p joins the working set in the first free slot (an add event)
-          const unsigned long long fm = __ballot(lane < KS && wcid < 0);
-          const int qslot = fm ? __ffsll((long long)fm) - 1 : -1;
-          if (qslot < 0 || ((neva + 4) & ~3) + ((nevd + 3) & ~3) > KEV) {
-            retry = true;  // out of room: the robot is re-run with the Schur-form engine
-            break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        retry = run(std::true_type{}, gpool);
+      } else {
+        retry = run(std::false_type{}, nullptr);
+        if (spill && !retry) {
+          // ---- LDS pool full: take a slice of the overflow pool (one per robot and launch, handed out by a
+          // counter that the first kernel of the previous call cleared), move the records there -- add events
+          // from the bottom, drop events from the top, the rest of the group each side is in zeroed -- and go on
+          int slice = 0;
+          if (lane == 0) slice = P.ov_count ? atomicAdd(P.ov_count, 1) : P.ov_nslice;
+          slice = __builtin_amdgcn_readfirstlane(slice);
+          if (slice >= P.ov_nslice) {
+            retry = true;  // no slice left: the robot is re-run with the Schur-form engine
+          } else {
+            GlobalF64* const gpool = (GlobalF64*)P.ovpool + (size_t)slice * QMPC_OV_SLICE;
+            const double* lp_ = Sb.Sinv;
+            for (int e = 0; e < neva; ++e)
+              for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)e * EV + idx] = lp_[e * EV + idx];
+            for (int e = 0; e < nevd; ++e)
+              for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)(KEV_G - 1 - e) * EV + idx] = lp_[(KEV_L - 1 - e) * EV + idx];
+            for (int e = neva; e < (neva & ~3) + 4; ++e)
+              for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)e * EV + idx] = 0.0;
+            for (int e = (KEV_G - 1 - nevd) & ~3; e <= KEV_G - 1 - nevd; ++e)
+              for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)e * EV + idx] = 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            status |= QMPC_DEV_ST_SPILLED;  // informational
+            retry = run(std::true_type{}, gpool);
           }
-          const double s = rsqrt_full(delta);
-          double* en = pool + neva * EV;
-#pragma unroll
-          for (int q = 0; q < RE; ++q)
-            if (zw[q]) en[zo[q]] = z[q] * s;
-          if (lane < KS) en[NPE + lane] = (lane == qslot) ? s : ((wcid >= 0) ? -rw * s : 0.0);
-          if (lane == qslot) {
-            wcid = p_e;
-            lam = lp;
-          }
-          if (lane == psl) amask |= (1u << pty);
-          khw = (qslot + 1 > khw) ? qslot + 1 : khw;
-          neva += 1;
-          if (GPOOL && (neva & 3) == 0 && neva + 4 + ((nevd + 3) & ~3) <= KEV) zero_group(neva);
-          need_p = true;
-        } else {
-          // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event)
-          if (((neva + 3) & ~3) + ((nevd + 4) & ~3) > KEV) {
-            retry = true;
-            break;
-          }
-          if (!drop_slot(l, false)) break;
         }
-        __builtin_amdgcn_wave_barrier();
-        pool_sync();
-        if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
       }
       __builtin_amdgcn_s_setprio(0);
       QMPC_TICK(6);
@@ -2117,137 +2217,213 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 // The list counters are ping-ponged between consecutive solve calls: the
 // class-1 kernel of call N clears the set that call N+1 will use, so no memset
 // and no host round trip is needed.
-template <int RB, bool CMD, bool WARM = false>
-__global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
-  Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
-  // the first class launched takes robot = blockIdx.x and clears the NEXT call's list counters;
-  // every later class takes entry blockIdx.x of the list the previous classes filled
-  int rid = (int)blockIdx.x;
-  // (block index first: only block 0 waits for the kernel argument)
-  if (blockIdx.x == 0 && threadIdx.x < 3 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // one counter per list
-  if constexpr (RB != 1) {  // (class 1 is only ever launched first)
-    if (P.list) {
-      if ((int)blockIdx.x >= *P.count) return;  // uniform
-      rid = P.list[blockIdx.x];
-    }
-  }
+// one robot with the engine pair of its class: projected-inverse engine first; the (rare) robot that runs
+// out of pool is solved again from scratch with the Schur-form engine, which cannot overflow
+template <int RB, bool CMD, bool WARM>
+__device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<RB>& S, const QmpcParams& P) {
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
-    if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
-      // take a slice of the global event pool: slot = workgroup index modulo the slice count, guarded by a flag
-      // (a workgroup whose predecessor on that slice is still running -- it would have to be ~ev_nslot / 256
-      // times slower than average -- waits for it)
-      if (threadIdx.x == 0) {
-        const int slot = (int)(blockIdx.x % (unsigned)P.ev_nslot);
-        // (bounded: a flag left behind by an aborted launch must not hang this one; the host clears the flags
-        //  before every launch of this class anyway)
-        for (int spin = 0; spin < (1 << 16) && atomicCAS(&P.evflags[slot], 0, 1) != 0; ++spin) __builtin_amdgcn_s_sleep(8);
-        S.evslot = slot;
-      }
-      __syncthreads();
-    }
-    // projected-inverse engine first; the (rare) robot that runs out of pool is
-    // solved again from scratch with the Schur-form engine, which cannot overflow
-    const bool again = solve_one<RB, true, CMD, false, WARM>(rid, (int)threadIdx.x, S, P);
-    if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __threadfence();
-        atomicExch(&P.evflags[S.evslot], 0);
-      }
-    }
+    const bool again = solve_one<RB, true, CMD, false, WARM>(rid, tid, S, P);
     if (again) {
       __syncthreads();
       // opaque thread id: without it the compiler keeps per-thread values of the
       // first run alive (spilled to scratch by EVERY workgroup) for this rare second run
-      int tid2 = (int)threadIdx.x;
+      int tid2 = tid;
       asm volatile("" : "+v"(tid2));
       solve_one<RB, false, CMD, false, WARM>(rid, tid2, S, P);
       __syncthreads();
-      if (threadIdx.x == 0) P.status[rid] |= QMPC_DEV_ST_FALLBACK;  // informational
+      if (tid2 == 0) P.status[rid] |= QMPC_DEV_ST_FALLBACK;  // informational
     }
   } else {
-    solve_one<RB, false, CMD, false, WARM>(rid, (int)threadIdx.x, S, P);
+    solve_one<RB, false, CMD, false, WARM>(rid, tid, S, P);
+  }
+}
+
+// class 3: take a slice of the global event pool for the lifetime of the workgroup: slot = workgroup index
+// modulo the slice count, guarded by a flag (a workgroup whose predecessor on that slice is still running --
+// it would have to be ~ev_nslot / 256 times slower than average -- waits for it)
+template <int RB>
+__device__ __forceinline__ void pool_acquire(Smem<RB>& S, const QmpcParams& P) {
+  if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
+    if (threadIdx.x == 0) {
+      const int slot = (int)(blockIdx.x % (unsigned)P.ev_nslot);
+      // (bounded: a flag left behind by an aborted launch must not hang this one; the host clears the flags
+      //  before every launch of this class anyway)
+      for (int spin = 0; spin < (1 << 16) && atomicCAS(&P.evflags[slot], 0, 1) != 0; ++spin) __builtin_amdgcn_s_sleep(8);
+      S.evslot = slot;
+    }
+    __syncthreads();
+  }
+}
+template <int RB>
+__device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
+  if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      atomicExch(&P.evflags[S.evslot], 0);
+    }
+  }
+}
+
+#ifndef QMPC_LISTED_VARIANT
+#define QMPC_LISTED_VARIANT 2
+#endif
+
+// LISTED = false: the first class launched: robot = blockIdx.x; clears the NEXT call's list counters and queue
+// heads.  LISTED = true: every later class, launched with at most one workgroup per resident slot; it consumes
+// the list the previous classes filled as a queue: entry blockIdx.x first, then whatever entry the head counter
+// hands out.  (A grid of `batch` workgroups of which most find no entry costs more than the few solves
+// themselves: the no-op workgroups are dispatched at this class's LDS-limited occupancy.)
+template <int RB, bool CMD, bool WARM = false, bool LISTED = false>
+__global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
+  Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  if constexpr (!LISTED) {
+    // (block index first: only block 0 waits for the kernel argument)
+    if (blockIdx.x == 0 && threadIdx.x < 8 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // 3 counters + 3 heads
+    pool_acquire<RB>(S, P);
+    solve_robot<RB, CMD, WARM>((int)blockIdx.x, (int)threadIdx.x, S, P);
+    pool_release<RB>(S, P);
+  } else {
+    const int nlist = *P.count;
+    if ((int)blockIdx.x >= nlist) return;  // uniform
+    pool_acquire<RB>(S, P);
+    for (int idx = (int)blockIdx.x;;) {
+      const int rid = P.list[idx];
+      // opaque thread id per robot: nothing derived from it is loop-invariant, so the compiler cannot hoist
+      // per-thread values out of the loop (and spill them across the whole solve)
+      int tid1 = (int)threadIdx.x;
+#if QMPC_LISTED_VARIANT >= 1
+      asm volatile("" : "+v"(tid1));
+      __builtin_assume(tid1 >= 0 && tid1 < Cfg<RB>::NT);
+#endif
+#if QMPC_LISTED_VARIANT >= 2
+      // ... and an opaque kernel-argument pointer: the ~30 scalar loads of stage 0 stay inside the loop instead
+      // of being hoisted into SGPRs that then spill (the parameter block is the only explicit kernel argument,
+      // so it sits at offset 0 of the kernarg segment)
+      typedef const __attribute__((address_space(4))) QmpcParams* KernargPtr;
+      KernargPtr pk = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(pk));
+      const QmpcParams& PK = *(const QmpcParams*)pk;
+      solve_robot<RB, CMD, WARM>(rid, tid1, S, PK);
+#else
+      solve_robot<RB, CMD, WARM>(rid, tid1, S, P);
+#endif
+      __syncthreads();  // every wave is done with this robot's LDS state
+      if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+      __syncthreads();
+      idx = S.qnext;
+      if (idx >= nlist) break;  // uniform
+    }
+    pool_release<RB>(S, P);
   }
 }
 
 // JCQP alternate (update_solver_settings' use_jcqp = 1 / 2): same assembly and sweep, ADMM instead of the
 // active set; record mode only, same size-class chain
-template <int RB>
+template <int RB, bool LISTED = false>
 __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_admm_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
-  int rid = (int)blockIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x < 3 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
-  if (P.list) {
-    if ((int)blockIdx.x >= *P.count) return;  // uniform
-    rid = P.list[blockIdx.x];
+  if constexpr (!LISTED) {
+    if (blockIdx.x == 0 && threadIdx.x < 8 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+    solve_one<RB, false, false, true>((int)blockIdx.x, (int)threadIdx.x, S, P);
+  } else {  // list = queue, as in qmpc_solve_kernel
+    const int nlist = *P.count;
+    if ((int)blockIdx.x >= nlist) return;  // uniform
+    for (int idx = (int)blockIdx.x;;) {
+      const int rid = P.list[idx];
+      int tid1 = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid1));
+      __builtin_assume(tid1 >= 0 && tid1 < Cfg<RB>::NT);
+      solve_one<RB, false, false, true>(rid, tid1, S, P);
+      __syncthreads();
+      if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+      __syncthreads();
+      idx = S.qnext;
+      if (idx >= nlist) break;  // uniform
+    }
   }
-  solve_one<RB, false, false, true>(rid, (int)threadIdx.x, S, P);
-}
-
-extern "C" size_t qmpc_smem_bytes(int rb) {
-  switch (rb) {
-    case 1: return sizeof(Smem<1>);
-    case 2: return sizeof(Smem<2>);
-    case 3: return sizeof(Smem<3>);
-    case 4: return sizeof(Smem<4>);
-  }
-  return 0;
 }
 
 namespace {
-template <int RB, bool CMD>
-hipError_t prepare_one() {
-  return hipFuncSetAttribute((const void*)qmpc_solve_kernel<RB, CMD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)sizeof(Smem<RB>));
+template <typename K>
+hipError_t set_smem(K kernel, size_t bytes) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 template <int RB>
-hipError_t prepare_admm() {
-  hipError_t e = hipFuncSetAttribute((const void*)qmpc_solve_kernel<RB, false, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<RB>));
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)qmpc_admm_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)sizeof(Smem<RB>));
+hipError_t prepare_class() {
+  hipError_t e;
+  const size_t n = sizeof(Smem<RB>);
+  if ((e = set_smem(qmpc_solve_kernel<RB, false, false, false>, n)) != hipSuccess) return e;
+  if ((e = set_smem(qmpc_solve_kernel<RB, true, false, false>, n)) != hipSuccess) return e;
+  if ((e = set_smem(qmpc_solve_kernel<RB, false, true, false>, n)) != hipSuccess) return e;
+  if ((e = set_smem(qmpc_admm_kernel<RB, false>, n)) != hipSuccess) return e;
+  if constexpr (RB != 1) {  // (class 1 is only ever launched first)
+    if ((e = set_smem(qmpc_solve_kernel<RB, false, false, true>, n)) != hipSuccess) return e;
+    if ((e = set_smem(qmpc_solve_kernel<RB, true, false, true>, n)) != hipSuccess) return e;
+    if ((e = set_smem(qmpc_solve_kernel<RB, false, true, true>, n)) != hipSuccess) return e;
+    if ((e = set_smem(qmpc_admm_kernel<RB, true>, n)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+template <int RB, bool LISTED>
+void launch_variant(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
+  const dim3 g(grid), b(Cfg<RB>::NT);
+  const size_t n = sizeof(Smem<RB>);
+  if (P->admm_mode)
+    hipLaunchKernelGGL((qmpc_admm_kernel<RB, LISTED>), g, b, n, stream, *P);
+  else if (P->ws && !cmd)  // warm start across cycles: its own instantiation (record mode)
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, true, LISTED>), g, b, n, stream, *P);
+  else if (cmd)
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true, false, LISTED>), g, b, n, stream, *P);
+  else
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, false, LISTED>), g, b, n, stream, *P);
 }
 template <int RB>
 void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
-  if (P->admm_mode)
-    hipLaunchKernelGGL((qmpc_admm_kernel<RB>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
-  else if (P->ws && !cmd)  // warm start across cycles: its own instantiation (record mode)
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, true>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
-  else if (cmd)
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
-  else
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false>), dim3(grid), dim3(Cfg<RB>::NT), sizeof(Smem<RB>), stream, *P);
+  if constexpr (RB != 1) {
+    if (P->list) return launch_variant<RB, true>(cmd, P, grid, stream);
+  }
+  launch_variant<RB, false>(cmd, P, grid, stream);
 }
 }  // namespace
 
-extern "C" hipError_t qmpc_prepare(void) {
-  hipError_t e;
-  if ((e = prepare_one<1, false>()) != hipSuccess) return e;
-  if ((e = prepare_one<2, false>()) != hipSuccess) return e;
-  if ((e = prepare_one<3, false>()) != hipSuccess) return e;
-  if ((e = prepare_one<4, false>()) != hipSuccess) return e;
-  if ((e = prepare_one<4, true>()) != hipSuccess) return e;
-  if ((e = prepare_one<1, true>()) != hipSuccess) return e;
-  if ((e = prepare_one<2, true>()) != hipSuccess) return e;
-  if ((e = prepare_one<3, true>()) != hipSuccess) return e;
-  if ((e = prepare_admm<1>()) != hipSuccess) return e;
-  if ((e = prepare_admm<4>()) != hipSuccess) return e;
-  if ((e = prepare_admm<2>()) != hipSuccess) return e;
-  return prepare_admm<3>();
+// workgroups of the class that fit on the device at once (the grid of a list-consuming launch); the
+// instantiations of a class share LDS size and launch bounds, so the record-mode kernel stands for all of them
+template <int RB>
+int resident_class() {
+  static int cached = 0;
+  if (cached) return cached;
+  int dev = 0, cus = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, qmpc_solve_kernel<RB, false, false, RB != 1>,
+                                                                    Cfg<RB>::NT, sizeof(Smem<RB>));
+  if (e != hipSuccess || per < 1 || cus < 1) return 0;
+  return cached = per * cus;
 }
 
-// the command-mode instantiation is selected by P->c_position != nullptr
-extern "C" hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
-  const bool cmd = P->c_position != nullptr;
-  switch (rb) {
-    case 1: launch_one<1>(cmd, P, grid, stream); break;
-    case 2: launch_one<2>(cmd, P, grid, stream); break;
-    case 3: launch_one<3>(cmd, P, grid, stream); break;
-    case 4: launch_one<4>(cmd, P, grid, stream); break;
-    default: return hipErrorInvalidValue;
+// Host entry points, one set per size class (qmpc_capi.cpp dispatches on the class).  The file is compiled once
+// per class with -DQMPC_RB=<class> (four translation units built in parallel by __graft_entry__.build()), or
+// once without it for all four.  The command-mode instantiation is selected by P->c_position != nullptr.
+#define QMPC_DEFINE_CLASS(RB)                                                                              \
+  extern "C" size_t qmpc_c##RB##_smem(void) { return sizeof(Smem<RB>); }                                   \
+  extern "C" hipError_t qmpc_c##RB##_prepare(void) { return prepare_class<RB>(); }                         \
+  extern "C" int qmpc_c##RB##_resident(void) { return resident_class<RB>(); }                              \
+  extern "C" hipError_t qmpc_c##RB##_launch(const QmpcParams* P, int grid, hipStream_t stream) {           \
+    launch_one<RB>(P->c_position != nullptr, P, grid, stream);                                             \
+    return hipGetLastError();                                                                              \
   }
-  return hipGetLastError();
-}
+#if !defined(QMPC_RB) || QMPC_RB == 1
+QMPC_DEFINE_CLASS(1)
+#endif
+#if !defined(QMPC_RB) || QMPC_RB == 2
+QMPC_DEFINE_CLASS(2)
+#endif
+#if !defined(QMPC_RB) || QMPC_RB == 3
+QMPC_DEFINE_CLASS(3)
+#endif
+#if !defined(QMPC_RB) || QMPC_RB == 4
+QMPC_DEFINE_CLASS(4)
+#endif
