@@ -17,9 +17,11 @@
 
 // warm start: working-set slots kept per robot between MPC cycles (QMPC_WS_SLOTS of qmpc.h)
 #define QMPC_WS_STRIDE 64
-// one slice of a global event pool: 96 events x (192 rows + 64 slots) doubles (the largest class's record; the
-// smaller classes use the front of it)
+// one slice of the overflow event pool: 96 events x (128 rows + 64 slots) doubles fit (class 2's record, the largest
+// that spills; 96 x 256 allocated)
 #define QMPC_OV_SLICE (96 * 256)
+// ... and of the largest class's own pool: 96 events x (192 rows + 128 slots)
+#define QMPC_EV_SLICE3 (96 * 320)
 
 // leading dimension of the debug dump (largest padded size, 3 * 64)
 #define QMPC_DBG_LD 192
@@ -64,7 +66,7 @@ struct QmpcParams {
   // (1 = full problem, 2 = swing-eliminated) and the caller's settings (ConvexMPCLocomotion.cpp:644-648)
   int admm_mode, admm_max_iter;
   double admm_rho, admm_sigma, admm_alpha, admm_term;
-  // largest size class: event pool in global memory, ev_nslot slices of 96 x (192 + 64) doubles, one flag each
+  // largest size class: event pool in global memory, ev_nslot slices of QMPC_EV_SLICE3 doubles, one flag each
   double* evpool;
   int* evflags;
   int ev_nslot;

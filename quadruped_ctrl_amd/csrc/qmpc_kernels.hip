@@ -281,7 +281,7 @@ struct Cfg {
   // class 1 keeps 4 workgroups per CU and class 4 two
   static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176));
   static constexpr int NPOOL = POOL;
-  static constexpr int KS = (RB == 1) ? 32 : 64;  // event-form engine: working-set slot capacity (one per lane)
+  static constexpr int KS = (RB == 1) ? 32 : (RB == 3 ? 128 : 64);  // event-form engine: working-set slot capacity (class 3: two per lane)
   static constexpr bool EVENT_ENGINE = true;
   // class 3 has no LDS left for events: its event pool lives in global memory (one slice per workgroup in
   // flight, L2-resident: 96 events x 2 KB), the LDS pool only serves the Schur-form fallback
@@ -1318,6 +1318,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   } else if constexpr (V5) {
     if (engine) {
       constexpr int NPE = NP, KS = C::KS, EV = NPE + KS;
+      constexpr int KQ = (KS + 63) / 64;  // working-set slots per lane: slot s lives in lane s % 64, entry s / 64
       // event capacity: LDS pool of this class / a slice of a global pool (class 3: its only pool; the other
       // classes: where a robot continues when its LDS pool is full)
       constexpr int KEV_L = (C::NPOOL / EV) & ~3, KEV_G = C::KEV_GLOBAL;
@@ -1338,11 +1339,43 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // below stays in SGPRs instead of being carried through exec masks)
       auto uni = [](bool cnd) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(cnd) != 0ull; };
       unsigned amask = 0;  // stance-slot lane: bit ty = constraint (slot, ty) is in the working set
-      int wcid = -1;       // working-slot lane: constraint id in slot `lane`, -1 = free
-      double lam = 0.0;    // ... and its multiplier
+      int wcid[KQ];        // working-slot lane: constraint id in slot lane + 64 k, -1 = free
+      double lam[KQ];      // ... and its multiplier
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        wcid[k] = -1;
+        lam[k] = 0.0;
+      }
+      // value of working-set slot l (wave-uniform) out of a slot-lane array
+      auto slot_f64 = [&](const double (&v)[KQ], int l) __attribute__((always_inline)) {
+        double out = readlane_f64(v[0], l & 63);
+#pragma unroll
+        for (int k = 1; k < KQ; ++k) {
+          const double o = readlane_f64(v[k], l & 63);
+          if ((l >> 6) == k) out = o;
+        }
+        return out;
+      };
+      auto slot_i32 = [&](const int (&v)[KQ], int l) __attribute__((always_inline)) {
+        int out = __builtin_amdgcn_readlane(v[0], l & 63);
+#pragma unroll
+        for (int k = 1; k < KQ; ++k) {
+          const int o = __builtin_amdgcn_readlane(v[k], l & 63);
+          if ((l >> 6) == k) out = o;
+        }
+        return out;
+      };
       int khw = 0, status = 0, neva = 0, nevd = 0;
       bool need_p0 = true;  // (carried between the two runs; each run works on its own copy)
-      unsigned long long rbm = 0ull;  // compaction in progress: working-set slots whose add event is still to be rebuilt
+      unsigned long long rbm[KQ];  // compaction in progress: working-set slots whose add event is still to be rebuilt
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) rbm[k] = 0ull;
+      auto rb_any = [&]() __attribute__((always_inline)) {
+        unsigned long long m = rbm[0];
+#pragma unroll
+        for (int k = 1; k < KQ; ++k) m |= rbm[k];
+        return m != 0ull;
+      };
       bool spill = false;             // the LDS pool is full: continue on a slice of the overflow pool
       // ---- warm start (qmpc_set_warm_start): the previous cycle's working set, slid by `ws_shift`
       // horizon steps and mapped onto this cycle's stance slots, one candidate per lane.  The
@@ -1352,7 +1385,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // remains is a genuine Goldfarb-Idnani state (x optimal on W, multipliers >= 0) and the normal
       // iteration takes over.  The answer is the same unique minimiser; only the path is shorter.
       int cand = -1;
-      if (WARM && P.ws && lane < KS) {
+      if (WARM && P.ws && lane < (KS < QMPC_WS_STRIDE ? KS : QMPC_WS_STRIDE)) {
         const int eg = P.ws[(size_t)rid * QMPC_WS_STRIDE + lane];  // global id 5 * (4 step + foot) + type
         const int kg = (eg >= 0 ? eg / 5 : 0) - 4 * P.ws_shift;
         if (eg >= 0 && kg >= 0 && kg < nfs) {
@@ -1368,7 +1401,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       int rbl[RE];
 #pragma unroll
       for (int q = 0; q < RE; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
-      const int gl_off = NPE + (lane & (KS - 1));  // this lane's entry of an event's g~
+      int gl_off[KQ];  // this lane's entries of an event's g~
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) gl_off[k] = NPE + ((lane + 64 * k) & (KS - 1));
       auto gather = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
         double out = 0.0;
 #pragma unroll
@@ -1426,58 +1461,67 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         // minimiser of the problem WITHOUT that constraint: x -= (lam_l / gamma) u, lam -= (lam_l / gamma) sc.
         // Returns false when the projected inverse has lost definiteness numerically (retry is set).
         auto drop_slot = [&](int l, bool repair) __attribute__((always_inline)) {
-          double u[RE], sc = 0.0;
-  #pragma unroll
+          double u[RE], sc[KQ];
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) sc[k] = 0.0;
+#pragma unroll
           for (int q = 0; q < RE; ++q) u[q] = 0.0;
           auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;
-  #pragma unroll 1
+#pragma unroll 1
             for (int t0 = 0; t0 < cnt; t0 += 4) {
               const auto ev = pool + (base + DIR * t0) * EV;
-              double gll[4], zl[4][RE], gw[4];
-  #pragma unroll
+              double gll[4], zl[4][RE], gw[4][KQ];
+#pragma unroll
               for (int u4 = 0; u4 < 4; ++u4) {
                 const auto eu = ev + DIR * u4 * EV;
                 gll[u4] = eu[NPE + l];
-  #pragma unroll
+#pragma unroll
                 for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
-                gw[u4] = eu[gl_off];
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) gw[u4][k] = eu[gl_off[k]];
               }
-  #pragma unroll
+#pragma unroll
               for (int u4 = 0; u4 < 4; ++u4) {
-  #pragma unroll
+#pragma unroll
                 for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
-                sc = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4], sc);
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) sc[k] = __builtin_fma(DIR > 0 ? gll[u4] : -gll[u4], gw[u4][k], sc[k]);
               }
             }
           };
           dacc(std::integral_constant<int, 1>{}, 0, neva);
           if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
-          const double gamma = readlane_f64(sc, l);
+          const double gamma = slot_f64(sc, l);
           if (uni(!(gamma > 0.0))) {
             retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
             return false;
           }
           if (repair) {
-            const double coef = readlane_f64(lam, l) * fast_rcp(gamma);
-  #pragma unroll
+            const double coef = slot_f64(lam, l) * fast_rcp(gamma);
+#pragma unroll
             for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(-coef, u[q], xv[q]);
-            lam = __builtin_fma(-coef, sc, lam);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) lam[k] = __builtin_fma(-coef, sc[k], lam[k]);
           }
           const double sg = rsqrt_full(gamma);
-          const int de = __builtin_amdgcn_readlane(wcid, l);
+          const int de = slot_i32(wcid, l);
           const auto en = pool + (KEV - 1 - nevd) * EV;
-  #pragma unroll
+#pragma unroll
           for (int q = 0; q < RE; ++q)
             if (zw[q]) en[zo[q]] = u[q] * sg;
-          if (lane < KS) en[NPE + lane] = (lane == l || wcid < 0) ? 0.0 : -sc * sg;
+#pragma unroll
+          for (int k = 0; k < KQ; ++k)
+            if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
           // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
           for (int e = lane; e < neva; e += 64) pool[e * EV + NPE + l] = 0.0;
           for (int e = lane; e < nevd; e += 64) pool[(KEV - 1 - e) * EV + NPE + l] = 0.0;
-          if (lane == l) {
-            wcid = -1;
-            lam = 0.0;
-          }
+#pragma unroll
+          for (int k = 0; k < KQ; ++k)
+            if (lane + 64 * k == l) {
+              wcid[k] = -1;
+              lam[k] = 0.0;
+            }
           if (lane == de / 5) amask &= ~(1u << (de % 5));
           nevd += 1;
           if (GPOOL && (nevd & 3) == 0 && ((neva + 3) & ~3) + nevd + 4 <= KEV) zero_group(KEV - nevd - 4);
@@ -1505,7 +1549,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           // cancel.  With drop events in the pool: forget all records and rebuild the projected inverse from H^-1
           // with one add event per constraint that is in the working set NOW (x, the multipliers and the pending
           // constraint are untouched: the operators are the same, only their representation is shorter).
-          if (rbm == 0ull && ((neva + 4) & ~3) + ((nevd + 4) & ~3) > KEV) {
+          if (!rb_any() && ((neva + 4) & ~3) + ((nevd + 4) & ~3) > KEV) {
             if constexpr (!GPOOL) {
               spill = true;
               break;
@@ -1514,7 +1558,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                 retry = true;  // the working set alone fills the pool: the robot is re-run with the Schur-form engine
                 break;
               }
-              rbm = __ballot(lane < KS && wcid >= 0);
+#pragma unroll
+              for (int k = 0; k < KQ; ++k) rbm[k] = __ballot(lane + 64 * k < KS && wcid[k] >= 0);
               status |= QMPC_DEV_ST_COMPACTED;  // informational
               neva = 0;
               nevd = 0;
@@ -1524,12 +1569,18 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
               pool_sync();
             }
           }
-          const bool rebuild = GPOOL && rbm != 0ull;
+          const bool rebuild = GPOOL && rb_any();
           int rl = 0;
           if (rebuild) {
-            rl = __ffsll((long long)rbm) - 1;
-            rbm &= rbm - 1ull;
-            con_coefs(__builtin_amdgcn_readlane(wcid, rl), mi, pj1, pj2, pa1, pa2);
+            bool took = false;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k)
+              if (!took && rbm[k] != 0ull) {
+                rl = 64 * k + __ffsll((long long)rbm[k]) - 1;
+                rbm[k] &= rbm[k] - 1ull;
+                took = true;
+              }
+            con_coefs(slot_i32(wcid, rl), mi, pj1, pj2, pa1, pa2);
           } else {
           if (WARM && uni(need_p) && cmask != 0ull) {
             // ---- warm start: next candidate of the previous working set, forced
@@ -1546,8 +1597,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           } else if (WARM && uni(need_p) && fixneg) {
             // ---- warm start, second phase: a candidate whose multiplier is negative does not belong to
             // the working set -- remove it (one drop event) and move to the minimiser without it
-            const unsigned long long nm = __ballot(wcid >= 0 && lam < 0.0);
-            if (nm == 0ull) {
+            int l = -1;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+              const unsigned long long nm = __ballot(wcid[k] >= 0 && lam[k] < 0.0);
+              if (l < 0 && nm != 0ull) l = 64 * k + __ffsll((long long)nm) - 1;
+            }
+            if (l < 0) {
               fixneg = false;
               continue;
             }
@@ -1555,7 +1611,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
               retry = true;  // the guess cannot be repaired within the iteration limit: start over, cold, with the other engine
               break;
             }
-            const int l = __ffsll((long long)nm) - 1;
             if (!drop_slot(l, true)) break;
             iters += 1;
             continue;
@@ -1570,7 +1625,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
               double vmin = 0.0;
               int tmin = -1;
               const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx - x2};
-  #pragma unroll
+#pragma unroll
               for (int ty = 0; ty < 5; ++ty) {
                 const bool cand = !((amask >> ty) & 1u) && sv[ty] < vmin;
                 vmin = cand ? sv[ty] : vmin;
@@ -1597,35 +1652,39 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
           // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
           double z[RE];
-  #pragma unroll
+#pragma unroll
           for (int q = 0; q < RE; ++q) {
             const int row = lane + 64 * q;
             z[q] = (row < n) ? __builtin_fma(pa2, Hcol(q, pj2), pa1 * Hcol(q, pj1)) : 0.0;
           }
-          double rw = 0.0;
+          double rw[KQ];
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) rw[k] = 0.0;
           // four events per trip (rows past the last event are zero): y = z~^T c_p,
           // z -= +-y z~ , r += y g~
           auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
-  #pragma unroll 1
+#pragma unroll 1
             for (int t0 = 0; t0 < cnt; t0 += 4) {
               const auto ev = pool + (base + DIR * t0) * EV;
-              double ya[4], yb[4], zl[4][RE], gl[4];
-  #pragma unroll
+              double ya[4], yb[4], zl[4][RE], gl[4][KQ];
+#pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const auto eu = ev + DIR * u * EV;
                 ya[u] = eu[pj1];
                 yb[u] = eu[pj2];
-  #pragma unroll
+#pragma unroll
                 for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
-                gl[u] = eu[gl_off];
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) gl[u][k] = eu[gl_off[k]];
               }
-  #pragma unroll
+#pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
-  #pragma unroll
+#pragma unroll
                 for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
-                rw = __builtin_fma(y, gl[u], rw);
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) rw[k] = __builtin_fma(y, gl[u][k], rw[k]);
               }
             }
           };
@@ -1644,13 +1703,15 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             }
             const double s = rsqrt_full(delta);
             const auto en = pool + neva * EV;
-  #pragma unroll
+#pragma unroll
             for (int q = 0; q < RE; ++q)
               if (zw[q]) en[zo[q]] = z[q] * s;
-            if (lane < KS) en[NPE + lane] = (lane == rl) ? s : ((wcid >= 0) ? -rw * s : 0.0);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k)
+              if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == rl) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
             neva += 1;
             if (GPOOL && (neva & 3) == 0 && neva + 4 <= KEV) zero_group(neva);
-            if (rbm == 0ull && !need_p) con_coefs(p_e, mi, pj1, pj2, pa1, pa2);  // the pending constraint's coefficients again
+            if (!rb_any() && !need_p) con_coefs(p_e, mi, pj1, pj2, pa1, pa2);  // the pending constraint's coefficients again
             __builtin_amdgcn_wave_barrier();
             pool_sync();
             continue;
@@ -1660,16 +1721,27 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             continue;
           }
           const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
-          double ratio = __builtin_inf();
-          if (!(WARM && forced) && wcid >= 0 && rw > 0.0) {
-            const double qv = lam * fast_rcp(rw);
-            ratio = qv > 0.0 ? qv : 0.0;
+          double ratio[KQ], rmin = __builtin_inf();
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) {
+            ratio[k] = __builtin_inf();
+            if (!(WARM && forced) && wcid[k] >= 0 && rw[k] > 0.0) {
+              const double qv = lam[k] * fast_rcp(rw[k]);
+              ratio[k] = qv > 0.0 ? qv : 0.0;
+            }
+            rmin = (k == 0 || ratio[k] < rmin) ? ratio[k] : rmin;
           }
           double t1 = __builtin_inf();
           int l = -1;
           if (khw > 0 && !(WARM && forced)) {
-            t1 = wave_min_pos_f64(ratio);
-            if (uni(t1 < __builtin_inf())) l = __ffsll((long long)__ballot(ratio == t1)) - 1;
+            t1 = wave_min_pos_f64(rmin);
+            if (uni(t1 < __builtin_inf())) {
+#pragma unroll
+              for (int k = 0; k < KQ; ++k) {
+                const unsigned long long hit = __ballot(ratio[k] == t1);
+                if (l < 0 && hit != 0ull) l = 64 * k + __ffsll((long long)hit) - 1;
+              }
+            }
           }
           const double t = (t2 <= t1) ? t2 : t1;
           if (uni(!(t < __builtin_inf()))) {
@@ -1677,30 +1749,39 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             break;
           }
           if (!dep) {
-  #pragma unroll
+#pragma unroll
             for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(t, z[q], xv[q]);
           }
-          lam -= t * rw;
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) lam[k] -= t * rw[k];
           lp += t;
           iters += 1;
           if (uni(t2 <= t1)) {
             // ---- full step: p joins the working set in the first free slot (an add event)
-            const unsigned long long fm = __ballot(lane < KS && wcid < 0);
-            const int qslot = fm ? __ffsll((long long)fm) - 1 : -1;
+            int qslot = -1;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+              const unsigned long long fm = __ballot(lane + 64 * k < KS && wcid[k] < 0);
+              if (qslot < 0 && fm != 0ull) qslot = 64 * k + __ffsll((long long)fm) - 1;
+            }
             if (qslot < 0) {
               retry = true;  // out of working-set slots: the robot is re-run with the Schur-form engine
               break;
             }
             const double s = rsqrt_full(delta);
             const auto en = pool + neva * EV;
-  #pragma unroll
+#pragma unroll
             for (int q = 0; q < RE; ++q)
               if (zw[q]) en[zo[q]] = z[q] * s;
-            if (lane < KS) en[NPE + lane] = (lane == qslot) ? s : ((wcid >= 0) ? -rw * s : 0.0);
-            if (lane == qslot) {
-              wcid = p_e;
-              lam = lp;
-            }
+#pragma unroll
+            for (int k = 0; k < KQ; ++k)
+              if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == qslot) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k)
+              if (lane + 64 * k == qslot) {
+                wcid[k] = p_e;
+                lam[k] = lp;
+              }
             if (lane == psl) amask |= (1u << pty);
             khw = (qslot + 1 > khw) ? qslot + 1 : khw;
             neva += 1;
@@ -1788,8 +1869,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (cmdm) cmd_finish_state();
         }
         if (WARM && P.ws)  // the final working set, as global ids, for the next cycle's warm start
-          P.ws[(size_t)rid * QMPC_WS_STRIDE + lane] =
-              (lane < KS && wcid >= 0 && !dead) ? 5 * (int)S.sidx[wcid / 5] + (wcid % 5) : -1;
+          P.ws[(size_t)rid * QMPC_WS_STRIDE + lane] =  // (the first QMPC_WS_STRIDE slots; a guess need not be complete)
+              (lane < KS && wcid[0] >= 0 && !dead) ? 5 * (int)S.sidx[wcid[0] / 5] + (wcid[0] % 5) : -1;
         if (cmdm && P.f_ff) {
           float* fb = reinterpret_cast<float*>(Sb.D);  // diag(H^-1) is dead now
           if (lane < 12) fb[lane] = 0.f;
