@@ -726,6 +726,64 @@ def test_class3_working_set_beyond_48_slots(mpc_factory):
         assert np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0) < 1e-8
 
 
+def _solver_parity_on_own_qp(m, b, pick, tol=1e-8, nwsr=20000):
+    """Solve b with the QP dump on and compare the robots `pick(res)` selects with the reference's qpOASES
+    (iteration cap lifted) on the GPU's own assembled QP."""
+    Hd, gd, ld = m.debug_dump(b["batch"])
+    res = m.solve(b, full=True)
+    m.debug_off()
+    Hd, gd = Hd.cpu().numpy(), gd.cpu().numpy()
+    assert ((res["status"] & 47) == 0).all()
+    idx = pick(res)
+    worst, nact = 0.0, []
+    for i in idx:
+        H, g, A, lb, ub, x0 = O.assemble(b, i)
+        ve, Hr, gr, Ar, lr, ur = O.reduce(H, g, A, lb, ub)
+        n = gr.size
+        xq, y, used, rc, irc = O.qpoases(Hd[i][:n, :n], gd[i][:n], Ar, lr, ur, nwsr=nwsr)
+        assert rc == 0 and irc == 0
+        xs = res["soln"][i][~ve]
+        worst = max(worst, np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0))
+        ax = Ar @ xq
+        nact.append(int(((ax - lr < 1e-7) | (ur - ax < 1e-7)).sum()))   # rows at a bound at the solution
+    assert worst < tol, worst
+    return res, idx, worst, nact
+
+
+@pytest.mark.parametrize("mk,name", [(lambda: W.make_standing(384, 10), "standing h10 (128-row class)"),
+                                     (lambda: W.make_config(4, batch=4096), "configs[4] (64- and 96-row classes)")])
+def test_event_pool_overflow_continues_in_global_memory(mk, name, mpc_factory):
+    """A robot whose on-chip event pool fills up moves its records to a slice of the handle's overflow pool and
+    continues there (status bit 128, informational) instead of being re-solved: same answer as qpOASES on the
+    same QP, and the Schur-form engine is not needed for it."""
+    b = mk()
+    m = mpc_factory(b)
+    res, idx, worst, _ = _solver_parity_on_own_qp(m, b, lambda r: np.nonzero(r["status"] & 128)[0][:6])
+    print(name, "spilled robots", int(((res["status"] & 128) != 0).sum()), "checked", len(idx), "worst err", worst,
+          "fallback", int(((res["status"] & 16) != 0).sum()))
+    assert len(idx) >= 1
+    assert not (res["status"][idx] & 16).any()
+    # the overflow slices are handed out per call by a counter the previous call re-armed: same result every time
+    for _ in range(3):
+        again = m.solve(b, full=True)
+        assert np.array_equal(again["soln"], res["soln"]) and np.array_equal(again["status"], res["status"])
+
+
+def test_class3_more_than_64_working_constraints(mpc_factory):
+    """All four feet down at horizon 16 (n_r = 192), hard commands: a few robots of every batch end with more
+    than 64 constraints in the working set.  The 192-row class holds 128 (two per engine lane), so they are
+    solved by the fast engine -- before, they were re-solved by the Schur-form engine, which at n_r = 192 has
+    48 slots and reported WS_FULL."""
+    b = W.make_standing(1024, 16)
+    m = mpc_factory(b)
+    m.set_min_stance(64)
+    res, idx, worst, nact = _solver_parity_on_own_qp(m, b, lambda r: np.argsort(r["iters"])[-3:])
+    print("three hardest robots: iters", res["iters"][idx].tolist(), "rows at a bound", nact, "worst err", worst,
+          "fallback", int(((res["status"] & 16) != 0).sum()))
+    assert max(nact) > 64
+    assert not (res["status"] & 16).any()
+
+
 @pytest.mark.parametrize("B,h,omni,stand,calm", [(192, 10, 0, 0.15, False), (70, 16, 1, 0.3, True), (33, 14, 0, 1.0, True)])
 def test_fused_command_solve_is_bit_identical_to_the_three_calls(B, h, omni, stand, calm, mpc_factory):
     """qmpc_solve_commands (record generated in stage 0, state updated and forces rotated in the
