@@ -336,6 +336,9 @@ struct Smem {
 };
 
 // phase timestamps (profiling hook; dbg_clk == nullptr in production)
+#ifndef QMPC_DBG_ITER
+#define QMPC_DBG_ITER 0  // the event-engine iteration the stamps 8 / 9 / 10 are taken in (> 0: stamp 14 = its start; tools/iter_phase.py)
+#endif
 // fine-grained stamps inside the FIRST active-set iteration
 #define QMPC_TICK1(k)                                                \
   do {                                                               \
@@ -1322,6 +1325,12 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // event capacity: LDS pool of this class / a slice of a global pool (class 3: its only pool; the other
       // classes: where a robot continues when its LDS pool is full)
       constexpr int KEV_L = (C::NPOOL / EV) & ~3, KEV_G = C::KEV_GLOBAL;
+#ifndef QMPC_TR_G
+#define QMPC_TR_G 4
+#endif
+      // events per trip on a global pool.  (8 -- twice the loads in flight per wait -- measured: no faster, the
+      // accumulation pays ~22 cycles per load instruction whatever the trip length, and it costs 20 VGPRs)
+      constexpr int TR_G = QMPC_TR_G;
       // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
       // 96 rows in two 64-lane blocks) read entry 0 -- harmless, those rows are never used -- and
       // do not write
@@ -1346,25 +1355,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         wcid[k] = -1;
         lam[k] = 0.0;
       }
-      // value of working-set slot l (wave-uniform) out of a slot-lane array
-      auto slot_f64 = [&](const double (&v)[KQ], int l) __attribute__((always_inline)) {
-        double out = readlane_f64(v[0], l & 63);
-#pragma unroll
-        for (int k = 1; k < KQ; ++k) {
-          const double o = readlane_f64(v[k], l & 63);
-          if ((l >> 6) == k) out = o;
-        }
-        return out;
-      };
-      auto slot_i32 = [&](const int (&v)[KQ], int l) __attribute__((always_inline)) {
-        int out = __builtin_amdgcn_readlane(v[0], l & 63);
-#pragma unroll
-        for (int k = 1; k < KQ; ++k) {
-          const int o = __builtin_amdgcn_readlane(v[k], l & 63);
-          if ((l >> 6) == k) out = o;
-        }
-        return out;
-      };
       int khw = 0, status = 0, neva = 0, nevd = 0;
       bool need_p0 = true;  // (carried between the two runs; each run works on its own copy)
       unsigned long long rbm[KQ];  // compaction in progress: working-set slots whose add event is still to be rebuilt
@@ -1437,6 +1427,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       auto run = [&](auto gpc, GlobalF64* const gpool) __attribute__((always_inline)) {
         constexpr bool GPOOL = decltype(gpc)::value;
         constexpr int KEV = GPOOL ? KEV_G : KEV_L;
+        constexpr int TR = GPOOL ? TR_G : 4;  // events per trip of the accumulation loops
         // (locals, not captures: a flag that nested lambdas reach through two closures ends up in scratch)
         bool need_p = need_p0, retry = false;
         const auto pool = [&]() __attribute__((always_inline)) {
@@ -1446,10 +1437,12 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         // per trip).  The LDS pool is zeroed wholesale beforehand; the global pool lazily, one group ahead
         auto zero_group = [&](int first) __attribute__((always_inline)) {
           if constexpr (GPOOL) {
-            if (first >= 0 && first + 4 <= KEV)
-              for (int idx = lane; idx < 4 * EV; idx += 64) pool[(size_t)first * EV + idx] = 0.0;
+            if (first >= 0 && first + TR <= KEV)
+              for (int idx = lane; idx < TR * EV; idx += 64) pool[(size_t)first * EV + idx] = 0.0;
           }
         };
+        // (global pool: called by the READERS of the pool, right before they start -- the stores of the previous
+        //  step complete while the next constraint is being selected, not while the wave waits for them)
         auto pool_sync = [&]() __attribute__((always_inline)) {
           if constexpr (GPOOL) {  // event rows written by some lanes are read by others of this wave through L1 / L2
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1464,16 +1457,17 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           double u[RE], sc[KQ];
 #pragma unroll
           for (int k = 0; k < KQ; ++k) sc[k] = 0.0;
+          pool_sync();
 #pragma unroll
           for (int q = 0; q < RE; ++q) u[q] = 0.0;
           auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;
 #pragma unroll 1
-            for (int t0 = 0; t0 < cnt; t0 += 4) {
+            for (int t0 = 0; t0 < cnt; t0 += TR) {
               const auto ev = pool + (base + DIR * t0) * EV;
-              double gll[4], zl[4][RE], gw[4][KQ];
+              double gll[TR], zl[TR][RE], gw[TR][KQ];
 #pragma unroll
-              for (int u4 = 0; u4 < 4; ++u4) {
+              for (int u4 = 0; u4 < TR; ++u4) {
                 const auto eu = ev + DIR * u4 * EV;
                 gll[u4] = eu[NPE + l];
 #pragma unroll
@@ -1482,7 +1476,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                 for (int k = 0; k < KQ; ++k) gw[u4][k] = eu[gl_off[k]];
               }
 #pragma unroll
-              for (int u4 = 0; u4 < 4; ++u4) {
+              for (int u4 = 0; u4 < TR; ++u4) {
 #pragma unroll
                 for (int q = 0; q < RE; ++q) u[q] = __builtin_fma(gll[u4], zl[u4][q], u[q]);
 #pragma unroll
@@ -1492,20 +1486,20 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           };
           dacc(std::integral_constant<int, 1>{}, 0, neva);
           if (nevd > 0) dacc(std::integral_constant<int, -1>{}, KEV - 1, nevd);
-          const double gamma = slot_f64(sc, l);
+          const double gamma = lane_elem<KQ>(sc, l);
           if (uni(!(gamma > 0.0))) {
             retry = true;  // numerically lost S^-1[l][l] > 0: start over with the other engine
             return false;
           }
           if (repair) {
-            const double coef = slot_f64(lam, l) * fast_rcp(gamma);
+            const double coef = lane_elem<KQ>(lam, l) * fast_rcp(gamma);
 #pragma unroll
             for (int q = 0; q < RE; ++q) xv[q] = __builtin_fma(-coef, u[q], xv[q]);
 #pragma unroll
             for (int k = 0; k < KQ; ++k) lam[k] = __builtin_fma(-coef, sc[k], lam[k]);
           }
           const double sg = rsqrt_full(gamma);
-          const int de = slot_i32(wcid, l);
+          const int de = lane_elem<KQ>(wcid, l);
           const auto en = pool + (KEV - 1 - nevd) * EV;
 #pragma unroll
           for (int q = 0; q < RE; ++q)
@@ -1524,9 +1518,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             }
           if (lane == de / 5) amask &= ~(1u << (de % 5));
           nevd += 1;
-          if (GPOOL && (nevd & 3) == 0 && ((neva + 3) & ~3) + nevd + 4 <= KEV) zero_group(KEV - nevd - 4);
+          if (GPOOL && (nevd & (TR - 1)) == 0 && ((neva + TR - 1) & ~(TR - 1)) + nevd + TR <= KEV) zero_group(KEV - nevd - TR);
           __builtin_amdgcn_wave_barrier();
-          pool_sync();
           return true;
         };
 
@@ -1542,6 +1535,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           pty = __builtin_amdgcn_readfirstlane(pty);
           pj1 = __builtin_amdgcn_readfirstlane(pj1);
           pj2 = __builtin_amdgcn_readfirstlane(pj2);
+          if (QMPC_DBG_ITER > 0 && dbg_clk && lane == 0 && iters == QMPC_DBG_ITER) dbg_clk[14] = clock64();
           // ---- room for one more event of either kind?  Checked here, between iterations, where the state is
           // consistent.  LDS pool: no -> leave the loop, the events move to this robot's slice of the overflow pool
           // in global memory and the iteration continues there (`spill`).  Global pool: no -> compaction.  Every
@@ -1549,7 +1543,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           // cancel.  With drop events in the pool: forget all records and rebuild the projected inverse from H^-1
           // with one add event per constraint that is in the working set NOW (x, the multipliers and the pending
           // constraint are untouched: the operators are the same, only their representation is shorter).
-          if (!rb_any() && ((neva + 4) & ~3) + ((nevd + 4) & ~3) > KEV) {
+          if (!rb_any() && ((neva + TR) & ~(TR - 1)) + ((nevd + TR) & ~(TR - 1)) > KEV) {
             if constexpr (!GPOOL) {
               spill = true;
               break;
@@ -1564,9 +1558,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
               neva = 0;
               nevd = 0;
               zero_group(0);
-              zero_group(KEV - 4);
+              zero_group(KEV - TR);
               __builtin_amdgcn_wave_barrier();
-              pool_sync();
             }
           }
           const bool rebuild = GPOOL && rb_any();
@@ -1580,7 +1573,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                 rbm[k] &= rbm[k] - 1ull;
                 took = true;
               }
-            con_coefs(slot_i32(wcid, rl), mi, pj1, pj2, pa1, pa2);
+            con_coefs(lane_elem<KQ>(wcid, rl), mi, pj1, pj2, pa1, pa2);
           } else {
           if (WARM && uni(need_p) && cmask != 0ull) {
             // ---- warm start: next candidate of the previous working set, forced
@@ -1649,7 +1642,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             forced = false;
           }
           }  // (!rebuild)
-          if (dbg_clk && lane == 0 && iters == 0) dbg_clk[8] = clock64();
+          if (dbg_clk && lane == 0 && iters == QMPC_DBG_ITER) dbg_clk[8] = clock64();
           // ---- z = P c_p (index-major lanes), r = N*^T c_p (slot lanes)
           double z[RE];
 #pragma unroll
@@ -1660,16 +1653,27 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           double rw[KQ];
 #pragma unroll
           for (int k = 0; k < KQ; ++k) rw[k] = 0.0;
+          pool_sync();
+          if (QMPC_DBG_ITER > 0 && dbg_clk && lane == 0 && iters == QMPC_DBG_ITER) {
+            double zs = 0.0;  // (the stamp waits for z)
+#pragma unroll
+            for (int q = 0; q < RE; ++q) zs += z[q];
+            asm volatile("" ::"v"(zs));
+            dbg_clk[15] = clock64();
+          }
           // four events per trip (rows past the last event are zero): y = z~^T c_p,
           // z -= +-y z~ , r += y g~
+          // (measured, not kept: computing every event's y first -- one lane per event -- and streaming the rows
+          //  afterwards saves two loads and two multiply-adds per event; +5 % for the 128-row class, -1 % for the
+          //  64- and 96-row classes whose robots hold few events)
           auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
 #pragma unroll 1
-            for (int t0 = 0; t0 < cnt; t0 += 4) {
+            for (int t0 = 0; t0 < cnt; t0 += TR) {
               const auto ev = pool + (base + DIR * t0) * EV;
-              double ya[4], yb[4], zl[4][RE], gl[4][KQ];
+              double ya[TR], yb[TR], zl[TR][RE], gl[TR][KQ];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
+              for (int u = 0; u < TR; ++u) {
                 const auto eu = ev + DIR * u * EV;
                 ya[u] = eu[pj1];
                 yb[u] = eu[pj2];
@@ -1679,7 +1683,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                 for (int k = 0; k < KQ; ++k) gl[u][k] = eu[gl_off[k]];
               }
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
+              for (int u = 0; u < TR; ++u) {
                 const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
 #pragma unroll
                 for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
@@ -1693,7 +1697,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           const double delta = __builtin_fma(pa2, bcast(z, pj2), pa1 * bcast(z, pj1));
           const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
           const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
-          if (dbg_clk && lane == 0 && iters == 0) dbg_clk[9] = clock64();
+          if (dbg_clk && lane == 0 && iters == QMPC_DBG_ITER) dbg_clk[9] = clock64();
           const bool dep = uni(!(delta > 1e-11 * cn));
           if (rebuild) {
             // the add event of slot rl, exactly as in the full step below (r is zero for the slots not rebuilt yet)
@@ -1710,10 +1714,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             for (int k = 0; k < KQ; ++k)
               if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == rl) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
             neva += 1;
-            if (GPOOL && (neva & 3) == 0 && neva + 4 <= KEV) zero_group(neva);
+            if (GPOOL && (neva & (TR - 1)) == 0 && neva + TR <= KEV) zero_group(neva);
             if (!rb_any() && !need_p) con_coefs(p_e, mi, pj1, pj2, pa1, pa2);  // the pending constraint's coefficients again
             __builtin_amdgcn_wave_barrier();
-            pool_sync();
             continue;
           }
           if (WARM && forced && dep) {  // a candidate that depends on the ones already added: skip it
@@ -1785,15 +1788,14 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             if (lane == psl) amask |= (1u << pty);
             khw = (qslot + 1 > khw) ? qslot + 1 : khw;
             neva += 1;
-            if (GPOOL && (neva & 3) == 0 && neva + 4 + ((nevd + 3) & ~3) <= KEV) zero_group(neva);
+            if (GPOOL && (neva & (TR - 1)) == 0 && neva + TR + ((nevd + TR - 1) & ~(TR - 1)) <= KEV) zero_group(neva);
             need_p = true;
           } else {
             // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event)
             if (!drop_slot(l, false)) break;
           }
           __builtin_amdgcn_wave_barrier();
-          pool_sync();
-          if (dbg_clk && lane == 0 && iters == 1) dbg_clk[10] = clock64();
+          if (dbg_clk && lane == 0 && iters == QMPC_DBG_ITER + 1) dbg_clk[10] = clock64();
         }
         need_p0 = need_p;
         return retry;
@@ -1802,9 +1804,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       if constexpr (C::GLOBAL_EVENTS) {
         // (this workgroup's slice of the class's pool, taken in the kernel prologue)
         GlobalF64* const gpool = (GlobalF64*)P.evpool + (size_t)S.evslot * ((size_t)KEV_G * EV);
-        for (int idx = lane; idx < 4 * EV; idx += 64) {
+        for (int idx = lane; idx < TR_G * EV; idx += 64) {
           gpool[idx] = 0.0;
-          gpool[(size_t)(KEV_G - 4) * EV + idx] = 0.0;
+          gpool[(size_t)(KEV_G - TR_G) * EV + idx] = 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1827,9 +1829,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
               for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)e * EV + idx] = lp_[e * EV + idx];
             for (int e = 0; e < nevd; ++e)
               for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)(KEV_G - 1 - e) * EV + idx] = lp_[(KEV_L - 1 - e) * EV + idx];
-            for (int e = neva; e < (neva & ~3) + 4; ++e)
+            for (int e = neva; e < (neva & ~(TR_G - 1)) + TR_G; ++e)
               for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)e * EV + idx] = 0.0;
-            for (int e = (KEV_G - 1 - nevd) & ~3; e <= KEV_G - 1 - nevd; ++e)
+            for (int e = (KEV_G - 1 - nevd) & ~(TR_G - 1); e <= KEV_G - 1 - nevd; ++e)
               for (int idx = lane; idx < EV; idx += 64) gpool[(size_t)e * EV + idx] = 0.0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -11,6 +11,7 @@ for n in cfg1 standing_h10 standing_h14 standing_h16 trot_h16; do
 done
 cp gpurun_out/$T/shim_latency.json profiles/${T}_shim_latency.json
 cp gpurun_out/$T/warm_rollout.json profiles/${T}_warm_rollout.json
+cp gpurun_out/$T/class_stats.txt profiles/${T}_class_stats.txt 2>/dev/null || true
 python - "$T" <<'PY'
 import glob, json, os, sys
 T = sys.argv[1]

@@ -26,6 +26,7 @@ run standing_h16 --workload standing --horizon 16
 run trot_h16 --config 3
 # bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
 for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
+for a in "--config 4 --batch 8192" "--workload standing --horizon 10 --batch 1024" "--workload standing --horizon 16 --batch 1024"; do python $R/tools/class_stats.py $a; done > $OUT/class_stats.txt 2>/dev/null
 for b in 256 4096 16384 65536; do python $R/bench.py --steps 100 --batch $b --no-cpu-baseline --no-pipelined > $OUT/bench_cfg1_b$b.json 2>/dev/null; done
 python $R/bench.py --steps 100 --caller-side fused --no-cpu-baseline > $OUT/bench_caller_fused.json 2>/dev/null
 python $R/tools/shim_latency.py > $OUT/shim_latency.json 2> $OUT/shim_latency.err
