@@ -162,7 +162,7 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 11; }
+int qmpc_abi_version(void) { return 12; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -331,6 +331,14 @@ int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_H = H_dev;
   c->dbg_g = g_dev;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug_overflow_slices(qmpc_handle c, int n) {
+  if (!c) return QMPC_ERR_ARG;
+  const int all = c->max_batch < 256 ? c->max_batch : 256;  // what qmpc_create allocated
+  if (n > all) return QMPC_ERR_ARG;  // more slices than allocated
+  c->ov_nslice = n < 0 ? all : n;
   return QMPC_OK;
 }
 

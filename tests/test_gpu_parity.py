@@ -769,6 +769,29 @@ def test_event_pool_overflow_continues_in_global_memory(mk, name, mpc_factory):
         assert np.array_equal(again["soln"], res["soln"]) and np.array_equal(again["status"], res["status"])
 
 
+def test_overflow_pool_exhausted_falls_back(mpc_factory):
+    """More robots run out of on-chip pool in one call than the handle has overflow slices (cut to 2 with the
+    test hook): the surplus is re-solved by the Schur-form engine (bit 16), everybody gets the same answer as
+    with all slices, and every call starts with all slices free again."""
+    b = W.make_standing(1024, 10)
+    m = mpc_factory(b)
+    base = m.solve(b, full=True)
+    sp = np.nonzero(base["status"] & 128)[0]
+    assert len(sp) >= 4 and not (base["status"] & 16).any() and ((base["status"] & 47) == 0).all()
+    m.debug_overflow_slices(2)
+    for _ in range(2):
+        cut = m.solve(b, full=True)
+        assert ((cut["status"] & 47) == 0).all()
+        assert int(((cut["status"] & 128) != 0).sum()) == 2 and int(((cut["status"] & 16) != 0).sum()) == len(sp) - 2
+        assert set(np.nonzero(cut["status"] & (128 | 16))[0]) == set(sp)
+        scale = np.abs(base["soln"]).max(1).clip(1.0)
+        assert (np.abs(cut["soln"] - base["soln"]).max(1) / scale).max() < 1e-9     # two engines, one minimiser
+        rest = np.setdiff1d(np.arange(1024), sp)
+        assert np.array_equal(cut["soln"][rest], base["soln"][rest])
+    m.debug_overflow_slices(-1)
+    assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+
+
 def test_class3_more_than_64_working_constraints(mpc_factory):
     """All four feet down at horizon 16 (n_r = 192), hard commands: a few robots of every batch end with more
     than 64 constraints in the working set.  The 192-row class holds 128 (two per engine lane), so they are
