@@ -287,6 +287,13 @@ struct Cfg {
   // flight, L2-resident: 96 events x 2 KB), the LDS pool only serves the Schur-form fallback
   static constexpr bool GLOBAL_EVENTS = (RB == 3);
   static constexpr int KEV_GLOBAL = 96;
+  // waves 1..NHELP take a share of the stored events whenever there are enough of them to be worth two barriers
+  // (the larger classes: long active-set runs, and seven or eleven waves with nothing else to do)
+  static constexpr int NHELP = (RB == 1) ? 0 : 3;
+#ifndef QMPC_HELP_MIN_TRIPS
+#define QMPC_HELP_MIN_TRIPS 3
+#endif
+  static constexpr int HELP_MIN_TRIPS = QMPC_HELP_MIN_TRIPS;
   static constexpr int MIN_WAVES = (RB == 1 || RB == 4) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
 };
 
@@ -302,6 +309,13 @@ struct Smem {
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   int evslot;  // class 3: this workgroup's slice of the global event pool
   int qnext;   // next entry of the work list (classes launched after the first)
+  // the engine wave's request to the helper waves (event-form engine, classes with NHELP > 0)
+  struct Help {
+    int cmd;  // 0 = the solve is over, 1 = accumulate your share of the events
+    int pj1, pj2, neva, nevd, glob;
+    double pa1, pa2;
+    unsigned long long gptr;  // the global pool slice when glob != 0
+  } hd;
   // ---- phase-local storage
   union U {
     struct AW {
@@ -1319,28 +1333,76 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       }
     }
   } else if constexpr (V5) {
-    if (engine) {
-      constexpr int NPE = NP, KS = C::KS, EV = NPE + KS;
-      constexpr int KQ = (KS + 63) / 64;  // working-set slots per lane: slot s lives in lane s % 64, entry s / 64
-      // event capacity: LDS pool of this class / a slice of a global pool (class 3: its only pool; the other
-      // classes: where a robot continues when its LDS pool is full)
-      constexpr int KEV_L = (C::NPOOL / EV) & ~3, KEV_G = C::KEV_GLOBAL;
+    constexpr int NPE = NP, KS = C::KS, EV = NPE + KS;
+    constexpr int KQ = (KS + 63) / 64;  // working-set slots per lane: slot s lives in lane s % 64, entry s / 64
+    // event capacity: LDS pool of this class / a slice of a global pool (class 3: its only pool; the other
+    // classes: where a robot continues when its LDS pool is full)
+    constexpr int NHELP = C::NHELP;
+    // (LDS pool: the last NHELP records' worth of it holds the helper waves' partial sums)
+    constexpr int KEV_L = ((C::NPOOL - (C::GLOBAL_EVENTS ? 0 : NHELP * EV)) / EV) & ~3, KEV_G = C::KEV_GLOBAL;
 #ifndef QMPC_TR_G
 #define QMPC_TR_G 4
 #endif
-      // events per trip on a global pool.  (8 -- twice the loads in flight per wait -- measured: no faster, the
-      // accumulation pays ~22 cycles per load instruction whatever the trip length, and it costs 20 VGPRs)
-      constexpr int TR_G = QMPC_TR_G;
-      // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
-      // 96 rows in two 64-lane blocks) read entry 0 -- harmless, those rows are never used -- and
-      // do not write
-      int zo[RE];
-      bool zw[RE];
+    // events per trip on a global pool.  (8 -- twice the loads in flight per wait -- measured: no faster, the
+    // accumulation pays ~22 cycles per load instruction whatever the trip length, and it costs 20 VGPRs)
+    constexpr int TR_G = QMPC_TR_G;
+    // this lane's entries of an index-major vector stored NP long: lanes past row NP (class 4:
+    // 96 rows in two 64-lane blocks) read entry 0 -- harmless, those rows are never used -- and
+    // do not write
+    int zo[RE];
+    bool zw[RE];
 #pragma unroll
-      for (int q = 0; q < RE; ++q) {
-        zw[q] = lane + 64 * q < NP;
-        zo[q] = zw[q] ? lane + 64 * q : 0;
+    for (int q = 0; q < RE; ++q) {
+      zw[q] = lane + 64 * q < NP;
+      zo[q] = zw[q] ? lane + 64 * q : 0;
+    }
+    int gl_off[KQ];  // this lane's entries of an event's g~
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) gl_off[k] = NPE + ((lane + 64 * k) & (KS - 1));
+    // where the helper waves leave their partial sums: NHELP records of (z[NP], r[KS]) behind the LDS event pool (the
+    // largest class keeps no events in LDS: the front of the pool)
+    double* const hpart = Sb.Sinv + (C::GLOBAL_EVENTS ? 0 : KEV_L * EV);
+    // z -= +-y z~ , r += y g~ with y = z~^T c_p over the stored events, four (TR) per trip; rows past the last event of
+    // a trip are zero.  Wave w of nw takes the trips w, w + nw, ... of the add events (front of the pool, DIR = +1)
+    // and then of the drop events (back of the pool, DIR = -1)
+    auto ev_part = [&](auto gpc, const auto pool, int pj1, int pj2, double pa1, double pa2, int neva, int nevd, int w, int nw,
+                       double (&z)[RE], double (&rw)[KQ]) __attribute__((always_inline)) {
+      constexpr bool GPOOL = decltype(gpc)::value;
+      constexpr int KEV = GPOOL ? KEV_G : KEV_L, TR = GPOOL ? TR_G : 4;
+      auto part = [&](auto dirc, int base, int cnt, int w0) __attribute__((always_inline)) {
+        constexpr int DIR = decltype(dirc)::value;
+#pragma unroll 1
+        for (int t0 = TR * w0; t0 < cnt; t0 += TR * nw) {
+          const auto ev = pool + (base + DIR * t0) * EV;
+          double ya[TR], yb[TR], zl[TR][RE], gl[TR][KQ];
+#pragma unroll
+          for (int u = 0; u < TR; ++u) {
+            const auto eu = ev + DIR * u * EV;
+            ya[u] = eu[pj1];
+            yb[u] = eu[pj2];
+#pragma unroll
+            for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) gl[u][k] = eu[gl_off[k]];
+          }
+#pragma unroll
+          for (int u = 0; u < TR; ++u) {
+            const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
+#pragma unroll
+            for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) rw[k] = __builtin_fma(y, gl[u][k], rw[k]);
+          }
+        }
+      };
+      part(std::integral_constant<int, 1>{}, 0, neva, w);
+      if (nevd > 0) {
+        // (the drop trips continue the round-robin where the add trips stopped)
+        const int ta = (neva + TR - 1) / TR;
+        part(std::integral_constant<int, -1>{}, KEV - 1, nevd, nw == 1 ? 0 : (w + nw - ta % nw) % nw);
       }
+    };
+    if (engine) {
       const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
       const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
       // wave-uniform predicate -> scalar branch (the operands are uniform but live in
@@ -1391,9 +1453,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       int rbl[RE];
 #pragma unroll
       for (int q = 0; q < RE; ++q) rbl[q] = (lane + 64 * q) * (lane + 64 * q + 1) / 2;
-      int gl_off[KQ];  // this lane's entries of an event's g~
-#pragma unroll
-      for (int k = 0; k < KQ; ++k) gl_off[k] = NPE + ((lane + 64 * k) & (KS - 1));
       auto gather = [&](const double (&v)[RE], int j) __attribute__((always_inline)) {
         double out = 0.0;
 #pragma unroll
@@ -1661,39 +1720,39 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             asm volatile("" ::"v"(zs));
             dbg_clk[15] = clock64();
           }
-          // four events per trip (rows past the last event are zero): y = z~^T c_p,
-          // z -= +-y z~ , r += y g~
           // (measured, not kept: computing every event's y first -- one lane per event -- and streaming the rows
           //  afterwards saves two loads and two multiply-adds per event; +5 % for the 128-row class, -1 % for the
           //  64- and 96-row classes whose robots hold few events)
-          auto accum = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
-            constexpr int DIR = decltype(dirc)::value;  // +1: add events, -1: drop events
-#pragma unroll 1
-            for (int t0 = 0; t0 < cnt; t0 += TR) {
-              const auto ev = pool + (base + DIR * t0) * EV;
-              double ya[TR], yb[TR], zl[TR][RE], gl[TR][KQ];
-#pragma unroll
-              for (int u = 0; u < TR; ++u) {
-                const auto eu = ev + DIR * u * EV;
-                ya[u] = eu[pj1];
-                yb[u] = eu[pj2];
-#pragma unroll
-                for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) gl[u][k] = eu[gl_off[k]];
+          bool helped = false;
+          if constexpr (NHELP > 0) {
+            // enough events for two barriers to pay: waves 1..NHELP take their share (fixed split, fixed order of the
+            // final sum: the result does not depend on timing)
+            if ((neva + TR - 1) / TR + (nevd + TR - 1) / TR >= C::HELP_MIN_TRIPS) {
+              helped = true;
+              if (lane == 0) {
+                S.hd.cmd = 1;
+                S.hd.pj1 = pj1;
+                S.hd.pj2 = pj2;
+                S.hd.neva = neva;
+                S.hd.nevd = nevd;
+                S.hd.glob = GPOOL ? 1 : 0;
+                S.hd.pa1 = pa1;
+                S.hd.pa2 = pa2;
+                if constexpr (GPOOL) S.hd.gptr = (unsigned long long)(size_t)pool;
               }
+              __syncthreads();  // (A) the request is up (and, global pool: this wave's event stores are drained)
+              ev_part(gpc, pool, pj1, pj2, pa1, pa2, neva, nevd, 0, NHELP + 1, z, rw);
+              __syncthreads();  // (B) the partial sums are in LDS
 #pragma unroll
-              for (int u = 0; u < TR; ++u) {
-                const double y = __builtin_fma(pa2, yb[u], pa1 * ya[u]);
+              for (int w = 0; w < NHELP; ++w) {
 #pragma unroll
-                for (int q = 0; q < RE; ++q) z[q] = __builtin_fma(DIR > 0 ? -y : y, zl[u][q], z[q]);
+                for (int q = 0; q < RE; ++q) z[q] += hpart[w * EV + zo[q]];
 #pragma unroll
-                for (int k = 0; k < KQ; ++k) rw[k] = __builtin_fma(y, gl[u][k], rw[k]);
+                for (int k = 0; k < KQ; ++k) rw[k] += hpart[w * EV + gl_off[k]];
               }
             }
-          };
-          accum(std::integral_constant<int, 1>{}, 0, neva);
-          if (nevd > 0) accum(std::integral_constant<int, -1>{}, KEV - 1, nevd);
+          }
+          if (!helped) ev_part(gpc, pool, pj1, pj2, pa1, pa2, neva, nevd, 0, 1, z, rw);
           const double delta = __builtin_fma(pa2, bcast(z, pj2), pa1 * bcast(z, pj1));
           const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
           const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
@@ -1841,6 +1900,10 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      if constexpr (NHELP > 0) {  // the helper waves leave their loop
+        if (lane == 0) S.hd.cmd = 0;
+        __syncthreads();
+      }
       QMPC_TICK(6);
       if (!retry) {
         // outputs: get_solution(0..11) = forces of the four feet at horizon step 0
@@ -1887,6 +1950,36 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         }
       }
       if (lane == 0) S.mode = retry ? 1 : 0;
+    } else if constexpr (NHELP > 0) {
+      // ---- every other wave: wait for a request; waves 1..NHELP accumulate their share of the events into a
+      // partial sum of their own (the remaining waves only keep the barrier count)
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      while (true) {
+        __syncthreads();  // (A)
+        if (__builtin_amdgcn_readfirstlane(S.hd.cmd) == 0) break;
+        if (wv <= NHELP) {
+          const int hj1 = __builtin_amdgcn_readfirstlane(S.hd.pj1), hj2 = __builtin_amdgcn_readfirstlane(S.hd.pj2);
+          const int hna = __builtin_amdgcn_readfirstlane(S.hd.neva), hnd = __builtin_amdgcn_readfirstlane(S.hd.nevd);
+          const double ha1 = S.hd.pa1, ha2 = S.hd.pa2;
+          double zp[RE], rp[KQ];
+#pragma unroll
+          for (int q = 0; q < RE; ++q) zp[q] = 0.0;
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) rp[k] = 0.0;
+          if (__builtin_amdgcn_readfirstlane(S.hd.glob) != 0)
+            ev_part(std::true_type{}, (GlobalF64*)(size_t)S.hd.gptr, hj1, hj2, ha1, ha2, hna, hnd, wv, NHELP + 1, zp, rp);
+          else
+            ev_part(std::false_type{}, (double*)Sb.Sinv, hj1, hj2, ha1, ha2, hna, hnd, wv, NHELP + 1, zp, rp);
+          double* const mine = hpart + (wv - 1) * EV;
+#pragma unroll
+          for (int q = 0; q < RE; ++q)
+            if (zw[q]) mine[zo[q]] = zp[q];
+#pragma unroll
+          for (int k = 0; k < KQ; ++k)
+            if (lane + 64 * k < KS) mine[NPE + lane + 64 * k] = rp[k];
+        }
+        __syncthreads();  // (B)
+      }
     }
   } else {
   // ------------------------------------------------------------ stage 5 (Schur form)
@@ -2294,12 +2387,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 
 }  // namespace
 
-// Class 1 (RB == 1): one workgroup per robot, robot = blockIdx.x.
-// Classes 4, 2, 3: workgroup b takes entry b of the list of robots the previous
-// class deferred (grid = batch; workgroups past the list length exit at once).
-// The list counters are ping-ponged between consecutive solve calls: the
-// class-1 kernel of call N clears the set that call N+1 will use, so no memset
-// and no host round trip is needed.
 // one robot with the engine pair of its class: projected-inverse engine first; the (rare) robot that runs
 // out of pool is solved again from scratch with the Schur-form engine, which cannot overflow
 template <int RB, bool CMD, bool WARM>
