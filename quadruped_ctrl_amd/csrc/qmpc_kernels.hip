@@ -47,6 +47,13 @@
 
 namespace {
 typedef __attribute__((address_space(1))) double GlobalF64;  // a double known to live in global memory (global_load, not flat_load)
+typedef double __attribute__((ext_vector_type(2))) F64x2;
+typedef __attribute__((address_space(1))) F64x2 GlobalF64x2;
+// two adjacent doubles with one 16-byte access (p 16-byte aligned)
+__device__ __forceinline__ F64x2 ld2(const double* p) { return *reinterpret_cast<const F64x2*>(p); }
+__device__ __forceinline__ F64x2 ld2(const GlobalF64* p) { return *reinterpret_cast<const GlobalF64x2*>(p); }
+__device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<F64x2*>(p) = F64x2{a, b}; }
+__device__ __forceinline__ void st2(GlobalF64* p, double a, double b) { *reinterpret_cast<GlobalF64x2*>(p) = F64x2{a, b}; }
 
 constexpr int WAVE = 64;
 #ifndef QMPC_ENGINE_PRIO
@@ -290,6 +297,12 @@ struct Cfg {
   // waves 1..NHELP take a share of the stored events whenever there are enough of them to be worth two barriers
   // (the larger classes: long active-set runs, and seven or eleven waves with nothing else to do)
   static constexpr int NHELP = (RB == 1) ? 0 : 3;
+  // event records with the lane's entries stored adjacently (16-byte loads): the classes whose robots hold many
+  // events; the record size is the same (NP and KS are multiples of 64 there)
+#ifndef QMPC_PAIRED
+#define QMPC_PAIRED 1
+#endif
+  static constexpr bool PAIRED = QMPC_PAIRED && (RB == 2 || RB == 3);
 #ifndef QMPC_HELP_MIN_TRIPS
 #define QMPC_HELP_MIN_TRIPS 3
 #endif
@@ -1359,6 +1372,64 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     int gl_off[KQ];  // this lane's entries of an event's g~
 #pragma unroll
     for (int k = 0; k < KQ; ++k) gl_off[k] = NPE + ((lane + 64 * k) & (KS - 1));
+    // ---- layout of an event record (z~[NP], g~[KS]).  Plain: z~ then g~, one entry per lane and 64-row block.
+    // PAIRED: what ONE LANE reads of a record is stored adjacently, so that it takes 16-byte loads -- the
+    // accumulation over the events is bound by the number of load instructions the CU's address unit takes
+    // (~22 cycles each, whichever wave issues them), not by bytes:
+    //   128-row class:  [lane](z[l], z[l+64])  |  [lane] g[l]                             2 loads instead of 3
+    //   192-row class:  [lane](z[l], z[l+64])  |  [lane](z[l+128], g[l])  |  [lane] g[l+64]      3 instead of 5
+    constexpr bool PAIRED = C::PAIRED;
+    static_assert(!PAIRED || (C::NH % 2 == 0 && NP % 64 == 0 && C::KS % 64 == 0), "paired records: 16-byte aligned pool, whole 64-lane blocks");
+    auto off_z = [](int j) __attribute__((always_inline)) {  // row j of z~
+      if constexpr (!PAIRED) return j;
+      else if constexpr (RE == 2) return 2 * (j & 63) + (j >> 6);
+      else return (j < 128) ? 2 * (j & 63) + (j >> 6) : 128 + 2 * (j & 63);
+    };
+    auto off_g = [](int sl) __attribute__((always_inline)) {  // slot sl of g~
+      if constexpr (!PAIRED) return NPE + sl;
+      else if constexpr (RE == 2) return 128 + sl;
+      else return (sl < 64) ? 128 + 2 * sl + 1 : 256 + (sl - 64);
+    };
+    // this lane's entries of a record: read ...
+    auto rec_load = [&](const auto eu, double (&zv)[RE], double (&gv)[KQ]) __attribute__((always_inline)) {
+      if constexpr (!PAIRED) {
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zv[q] = eu[zo[q]];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) gv[k] = eu[gl_off[k]];
+      } else {
+        const F64x2 a = ld2(eu + 2 * lane);
+        zv[0] = a.x;
+        zv[1] = a.y;
+        if constexpr (RE == 2) {
+          gv[0] = eu[128 + lane];
+        } else {
+          const F64x2 b2 = ld2(eu + 128 + 2 * lane);
+          zv[2] = b2.x;
+          gv[0] = b2.y;
+          gv[1] = eu[256 + lane];
+        }
+      }
+    };
+    // ... and written (rows past NP and slots past KS do not exist in the plain layout; PAIRED: NP, KS multiples of 64)
+    auto rec_store = [&](const auto en, const double (&zv)[RE], const double (&gv)[KQ]) __attribute__((always_inline)) {
+      if constexpr (!PAIRED) {
+#pragma unroll
+        for (int q = 0; q < RE; ++q)
+          if (zw[q]) en[zo[q]] = zv[q];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+          if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = gv[k];
+      } else {
+        st2(en + 2 * lane, zv[0], zv[1]);
+        if constexpr (RE == 2) {
+          en[128 + lane] = gv[0];
+        } else {
+          st2(en + 128 + 2 * lane, zv[2], gv[0]);
+          en[256 + lane] = gv[1];
+        }
+      }
+    };
     // where the helper waves leave their partial sums: NHELP records of (z[NP], r[KS]) behind the LDS event pool (the
     // largest class keeps no events in LDS: the front of the pool)
     double* const hpart = Sb.Sinv + (C::GLOBAL_EVENTS ? 0 : KEV_L * EV);
@@ -1369,6 +1440,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                        double (&z)[RE], double (&rw)[KQ]) __attribute__((always_inline)) {
       constexpr bool GPOOL = decltype(gpc)::value;
       constexpr int KEV = GPOOL ? KEV_G : KEV_L, TR = GPOOL ? TR_G : 4;
+      const int oj1 = off_z(pj1), oj2 = off_z(pj2);
       auto part = [&](auto dirc, int base, int cnt, int w0) __attribute__((always_inline)) {
         constexpr int DIR = decltype(dirc)::value;
 #pragma unroll 1
@@ -1378,12 +1450,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #pragma unroll
           for (int u = 0; u < TR; ++u) {
             const auto eu = ev + DIR * u * EV;
-            ya[u] = eu[pj1];
-            yb[u] = eu[pj2];
-#pragma unroll
-            for (int q = 0; q < RE; ++q) zl[u][q] = eu[zo[q]];
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) gl[u][k] = eu[gl_off[k]];
+            ya[u] = eu[oj1];
+            yb[u] = eu[oj2];
+            rec_load(eu, zl[u], gl[u]);
           }
 #pragma unroll
           for (int u = 0; u < TR; ++u) {
@@ -1519,6 +1588,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           pool_sync();
 #pragma unroll
           for (int q = 0; q < RE; ++q) u[q] = 0.0;
+          const int ogl = off_g(l);
           auto dacc = [&](auto dirc, int base, int cnt) __attribute__((always_inline)) {
             constexpr int DIR = decltype(dirc)::value;
 #pragma unroll 1
@@ -1528,11 +1598,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #pragma unroll
               for (int u4 = 0; u4 < TR; ++u4) {
                 const auto eu = ev + DIR * u4 * EV;
-                gll[u4] = eu[NPE + l];
-#pragma unroll
-                for (int q = 0; q < RE; ++q) zl[u4][q] = eu[zo[q]];
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) gw[u4][k] = eu[gl_off[k]];
+                gll[u4] = eu[ogl];
+                rec_load(eu, zl[u4], gw[u4]);
               }
 #pragma unroll
               for (int u4 = 0; u4 < TR; ++u4) {
@@ -1560,15 +1627,17 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           const double sg = rsqrt_full(gamma);
           const int de = lane_elem<KQ>(wcid, l);
           const auto en = pool + (KEV - 1 - nevd) * EV;
+          {
+            double zv[RE], gv[KQ];
 #pragma unroll
-          for (int q = 0; q < RE; ++q)
-            if (zw[q]) en[zo[q]] = u[q] * sg;
+            for (int q = 0; q < RE; ++q) zv[q] = u[q] * sg;
 #pragma unroll
-          for (int k = 0; k < KQ; ++k)
-            if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
+            for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
+            rec_store(en, zv, gv);
+          }
           // slot l leaves: column l of every earlier g~ is cleared (N*_l = 0, S^-1[l][:] = 0)
-          for (int e = lane; e < neva; e += 64) pool[e * EV + NPE + l] = 0.0;
-          for (int e = lane; e < nevd; e += 64) pool[(KEV - 1 - e) * EV + NPE + l] = 0.0;
+          for (int e = lane; e < neva; e += 64) pool[e * EV + ogl] = 0.0;
+          for (int e = lane; e < nevd; e += 64) pool[(KEV - 1 - e) * EV + ogl] = 0.0;
 #pragma unroll
           for (int k = 0; k < KQ; ++k)
             if (lane + 64 * k == l) {
@@ -1766,12 +1835,14 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             }
             const double s = rsqrt_full(delta);
             const auto en = pool + neva * EV;
+            {
+              double zv[RE], gv[KQ];
 #pragma unroll
-            for (int q = 0; q < RE; ++q)
-              if (zw[q]) en[zo[q]] = z[q] * s;
+              for (int q = 0; q < RE; ++q) zv[q] = z[q] * s;
 #pragma unroll
-            for (int k = 0; k < KQ; ++k)
-              if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == rl) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+              for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == rl) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+              rec_store(en, zv, gv);
+            }
             neva += 1;
             if (GPOOL && (neva & (TR - 1)) == 0 && neva + TR <= KEV) zero_group(neva);
             if (!rb_any() && !need_p) con_coefs(p_e, mi, pj1, pj2, pa1, pa2);  // the pending constraint's coefficients again
@@ -1832,12 +1903,14 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             }
             const double s = rsqrt_full(delta);
             const auto en = pool + neva * EV;
+            {
+              double zv[RE], gv[KQ];
 #pragma unroll
-            for (int q = 0; q < RE; ++q)
-              if (zw[q]) en[zo[q]] = z[q] * s;
+              for (int q = 0; q < RE; ++q) zv[q] = z[q] * s;
 #pragma unroll
-            for (int k = 0; k < KQ; ++k)
-              if (lane + 64 * k < KS) en[NPE + lane + 64 * k] = (lane + 64 * k == qslot) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+              for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == qslot) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+              rec_store(en, zv, gv);
+            }
 #pragma unroll
             for (int k = 0; k < KQ; ++k)
               if (lane + 64 * k == qslot) {
