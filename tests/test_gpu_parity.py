@@ -792,6 +792,50 @@ def test_overflow_pool_exhausted_falls_back(mpc_factory):
     assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
 
 
+def _take(b, idx):
+    out = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (b["batch"],) else v) for k, v in b.items()}
+    out["batch"] = len(idx)
+    return out
+
+
+@pytest.mark.parametrize("case", ["configs4", "configs4-admm", "standing-h14"])
+def test_result_does_not_depend_on_the_batch_around_a_robot(case, mpc_factory):
+    """A robot's answer is a function of its own record: solved inside a full shard or in a batch of a few dozen picked
+    robots, the solution, the iteration count and the status are bit-identical.  configs[4]: the 96-row class consumes
+    its work list as a queue (more listed robots than resident workgroups), overflow slices are handed out by a
+    counter, helper waves split the events; the same with the ADMM alternate (record mode 2), whose kernels take the
+    same queue.  Standing h=14, 2304 robots: more workgroups than the 192-row class has event-pool slices (2048), so
+    the late ones wait for and reuse the slice of an earlier robot."""
+    jcqp = 2 if case.endswith("admm") else 0
+    if case == "standing-h14":
+        b = W.make_standing(2304, 14)
+    else:
+        b = W.make_config(4, batch=2048 if jcqp else 8192)
+    B = b["batch"]
+    kw = dict(rho=1e-2, sigma=1e-6, terminate=1e-5, max_iter=400)
+    m = mpc_factory(b)
+    if jcqp:
+        m.settings_jcqp(jcqp, **kw)
+    full = m.solve(b, full=True)
+    rng = np.random.default_rng(5)
+    extra = [np.nonzero(full["status"] & 128)[0][:6], np.argsort(full["iters"])[-4:]]
+    if case == "standing-h14":
+        extra.append(np.arange(2048, 2304, 37))            # robots that run on a reused slice
+    else:
+        rows = 3 * (b["gait"] != 0).sum(1)
+        big = np.nonzero(rows > 64)[0]                     # the listed robots
+        assert len(big) > 600                              # > 512 resident workgroups of the 96-row class
+        extra += [big[:6], big[-12:]]
+    pick = np.unique(np.concatenate([rng.choice(B, 24, replace=False)] + extra))
+    sub = _take(b, pick)
+    m2 = mpc_factory(sub)
+    if jcqp:
+        m2.settings_jcqp(jcqp, **kw)
+    small = m2.solve(sub, full=True)
+    for k in ("soln", "iters", "status", "grf"):
+        assert np.array_equal(small[k], full[k][pick]), k
+
+
 def test_class3_more_than_64_working_constraints(mpc_factory):
     """All four feet down at horizon 16 (n_r = 192), hard commands: a few robots of every batch end with more
     than 64 constraints in the working set.  The 192-row class holds 128 (two per engine lane), so they are
