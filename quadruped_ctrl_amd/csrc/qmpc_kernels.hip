@@ -1068,33 +1068,47 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           const double u1 = fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0));
           // the CW pivot-column values of this column group, 16 per register (one per
           // lane of a row), broadcast inside the DPP fmac -- see fmac16_rowbcast
-#pragma unroll
-          for (int g = 0; g < CW / 16; ++g) {
+          auto upd16 = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
             const double cv0 = cb0[c * CW + 16 * g + (lane & 15)];
             const double cv1 = cb1[c * CW + 16 * g + (lane & 15)];
             double(&ag)[16] = *reinterpret_cast<double(*)[16]>(&a[16 * g]);
             fmac16_rowbcast(ag, cv0, -u0);
             fmac16_rowbcast(ag, cv1, -u1);
-          }
-          if constexpr (CW % 16 == 8) {  // class 4: the last eight columns of the group
+          };
+          auto upd8 = [&]() __attribute__((always_inline)) {  // class 4: the last eight columns of the group
             constexpr int G8 = CW - 8;
             const double cv0 = cb0[c * CW + G8 + (lane & 7)];
             const double cv1 = cb1[c * CW + G8 + (lane & 7)];
             double(&ag)[8] = *reinterpret_cast<double(*)[8]>(&a[G8]);
             fmac8_rowbcast(ag, cv0, -u0);
             fmac8_rowbcast(ag, cv1, -u1);
-          }
-          if (c == kb) {
-            // pivot columns <- F, pivot block <- -P^-1
-            a[r0] = p0 ? -i11 : (p1 ? i01 : fg0);
-            a[r1] = p0 ? i01 : (p1 ? -i00 : fg1);
-          }
+          };
+          // The sixteen (eight) columns that hold the NEXT pivot pair go first: their owner publishes the pair and
+          // the inverse of its 2x2 block while everybody, itself included, still updates the other columns -- the
+          // determinant / reciprocal / LDS-store chain leaves the critical path of the step (the order in which a
+          // thread updates its independent columns does not change a single bit of the result)
+          constexpr bool TAIL8 = (CW % 16 == 8);
+          constexpr bool NEXT_IN_TAIL = TAIL8 && (rn0 >= CW - 8);
+          constexpr int GNX = NEXT_IN_TAIL ? -1 : rn0 / 16;
+          if constexpr (NEXT_IN_TAIL) upd8();
+          else upd16(std::integral_constant<int, (GNX < 0 ? 0 : GNX)>{});
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
             Sw.colbuf[(m + 1) & 1][0][i] = a[rn0];
             Sw.colbuf[(m + 1) & 1][1][i] = a[rn1];
             const double e_n = lane_next(a[rn0]), d1_n = lane_next(a[rn1]);  // A[k1'][k0'], A[k1'][k1'] of the next pair
             if (i == k0 + 2) publish_pinv(a[rn0], e_n, d1_n, (m + 1) & 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          StaticFor<0, CW / 16>::run([&](auto gc) __attribute__((always_inline)) {
+            if constexpr (decltype(gc)::value != GNX) upd16(gc);
+          });
+          if constexpr (TAIL8 && !NEXT_IN_TAIL) upd8();
+          if (c == kb) {
+            // pivot columns <- F, pivot block <- -P^-1
+            a[r0] = p0 ? -i11 : (p1 ? i01 : fg0);
+            a[r1] = p0 ? i01 : (p1 ? -i00 : fg1);
           }
           __syncthreads();
         }
