@@ -463,9 +463,10 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     if (hc < nclass_eff) nclass_eff = hc;
   }
   if (nclass_eff == 4 && !c->d_evpool) {
-    // the 192-row class keeps its rank-1 events in global memory: one 192 KiB slice per workgroup in flight
-    // (256 CUs x 1 workgroup), 2048 slices so that a slice's previous tenant has long finished
-    const int nslot = c->max_batch < 2048 ? c->max_batch : 2048;
+    // the 192-row class keeps its rank-1 events in global memory: one 400 KiB slice (QMPC_EV_SLICE3) per workgroup in
+    // flight (256 CUs x 1 workgroup); 1024 flag-guarded slices, so that a slice's previous tenant has usually finished
+    // (a workgroup whose predecessor on its slice is still running waits for it)
+    const int nslot = c->max_batch < 1024 ? c->max_batch : 1024;
     HIP_TRY(c, hipMalloc(&c->d_evpool, sizeof(double) * (size_t)nslot * QMPC_EV_SLICE3));
     HIP_TRY(c, hipMalloc(&c->d_evflags, sizeof(int) * (size_t)nslot));
     HIP_TRY(c, hipMemset(c->d_evflags, 0, sizeof(int) * (size_t)nslot));

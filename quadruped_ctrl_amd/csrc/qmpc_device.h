@@ -20,8 +20,8 @@
 // one slice of the overflow event pool: 96 events x (128 rows + 64 slots) doubles fit (class 2's record, the largest
 // that spills; 96 x 256 allocated)
 #define QMPC_OV_SLICE (96 * 256)
-// ... and of the largest class's own pool: 96 events x (192 rows + 128 slots)
-#define QMPC_EV_SLICE3 (96 * 320)
+// ... and of the largest class's own pool: 160 events x (192 rows + 128 slots)
+#define QMPC_EV_SLICE3 (160 * 320)
 
 // leading dimension of the debug dump (largest padded size, 3 * 64)
 #define QMPC_DBG_LD 192

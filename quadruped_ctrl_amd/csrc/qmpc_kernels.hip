@@ -293,7 +293,9 @@ struct Cfg {
   // class 3 has no LDS left for events: its event pool lives in global memory (one slice per workgroup in
   // flight, L2-resident: 96 events x 2 KB), the LDS pool only serves the Schur-form fallback
   static constexpr bool GLOBAL_EVENTS = (RB == 3);
-  static constexpr int KEV_GLOBAL = 96;
+  // events a slice of a global pool holds.  Class 3's own pool: its 128 working-set slots plus room for drop events
+  // before a compaction (QMPC_EV_SLICE3); the overflow pool of the other classes (at most 64 slots): QMPC_OV_SLICE
+  static constexpr int KEV_GLOBAL = (RB == 3) ? 160 : 96;
   // waves 1..NHELP take a share of the stored events whenever there are enough of them to be worth two barriers
   // (the larger classes: long active-set runs, and seven or eleven waves with nothing else to do)
   static constexpr int NHELP = (RB == 1) ? 0 : 3;

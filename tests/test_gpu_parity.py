@@ -792,6 +792,22 @@ def test_overflow_pool_exhausted_falls_back(mpc_factory):
     assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
 
 
+def test_class3_working_sets_beyond_ninety_constraints_and_compaction(mpc_factory):
+    """All feet down at horizon 16, hard commands, force limit 40 N: up to 158 active-set iterations and working sets
+    of 100+ constraints.  The 192-row class's pool slice holds 160 events for its 128 slots (with 96, such robots
+    fell through to the Schur-form engine, which has 48 slots at n_r = 192, and ended WS_FULL); the occasional robot
+    that fills it with constraints that entered and left again compacts its records (bit 64) and goes on."""
+    cmd = W.make_commands(512, horizon=16, seed=11, stand_fraction=1.0)
+    b, _, _ = O.pack_commands(cmd, np.float32(0.026))
+    b.update(dt=0.026, mu=0.4, f_max=40.0)
+    m = mpc_factory(b)
+    pick = lambda r: np.unique(np.concatenate([np.argsort(r["iters"])[-3:], np.nonzero(r["status"] & 64)[0][:2]]))
+    res, idx, worst, nact = _solver_parity_on_own_qp(m, b, pick, tol=1e-7)
+    print("iters", res["iters"][idx].tolist(), "rows at a bound", nact, "compacted", int(((res["status"] & 64) != 0).sum()),
+          "fallback", int(((res["status"] & 16) != 0).sum()), "worst err", worst)
+    assert ((res["status"] & 47) == 0).all() and max(nact) > 90
+
+
 def _take(b, idx):
     out = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (b["batch"],) else v) for k, v in b.items()}
     out["batch"] = len(idx)
