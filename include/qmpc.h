@@ -227,7 +227,7 @@ int qmpc_debug_ld(qmpc_handle h);
  * quat_to_rpy (SolverMPC.cpp:257-267) -- so that a test can separate "same libm bits" from
  * "same algebra" when it compares the assembled QP with an fp64 model.  NULL = off. */
 int qmpc_set_debug_aux(qmpc_handle h, double* aux_dev);
-/* Test hook: use only the first n slices (0 <= n <= min(max_batch, 256)) of the handle's overflow event pool -- the
+/* Test hook: use only the first n slices (0 <= n <= min(max_batch, 1024)) of the handle's overflow event pool -- the
  * global-memory records a robot continues on when its on-chip event pool is full (QMPC_ST_SPILLED); robots that find
  * no slice are re-solved by the Schur-form engine (QMPC_ST_FALLBACK).  Negative n restores the default. */
 int qmpc_set_debug_overflow_slices(qmpc_handle h, int n);

@@ -185,7 +185,7 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) {
     // a robot whose on-chip event pool fills up continues here; more than ov_nslice of them in one launch chain
     // fall back to the Schur-form engine
-    c->ov_nslice = max_batch < 256 ? max_batch : 256;
+    c->ov_nslice = max_batch < 1024 ? max_batch : 1024;
     e = hipMalloc(&c->d_ovpool, sizeof(double) * (size_t)c->ov_nslice * QMPC_OV_SLICE);
   }
   if (e == hipSuccess) e = qmpc_prepare();
@@ -336,7 +336,7 @@ int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
 
 int qmpc_set_debug_overflow_slices(qmpc_handle c, int n) {
   if (!c) return QMPC_ERR_ARG;
-  const int all = c->max_batch < 256 ? c->max_batch : 256;  // what qmpc_create allocated
+  const int all = c->max_batch < 1024 ? c->max_batch : 1024;  // what qmpc_create allocated
   if (n > all) return QMPC_ERR_ARG;  // more slices than allocated
   c->ov_nslice = n < 0 ? all : n;
   return QMPC_OK;
