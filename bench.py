@@ -351,7 +351,9 @@ def main():
         flops = alg_flops_per_qp(h, nr_mean, float(iters.mean())) * per_gpu
         nr_max = 3 * int(nst.max())
         kclass = 1 if nr_max <= 64 else (4 if nr_max <= 96 else (2 if nr_max <= 128 else 3))
-        kname = f"qmpc_solve_kernel<{kclass}, {'true' if args.caller_side == 'fused' else 'false'}>"
+        # template arguments: <size class, command mode, warm start, list-consuming>; the dominant kernel of a uniform
+        # workload is the first of its chain (not list-consuming) -- the name rocprofv3 --kernel-trace --stats reports
+        kname = f"qmpc_solve_kernel<{kclass}, {'true' if args.caller_side == 'fused' else 'false'}, false, false>"
         t_s = step_ms_ev * 1e-3
         res = {
             "metric": "convex-MPC QP solves/sec (horizon=%d, 4-leg)" % h,
