@@ -25,12 +25,18 @@
 //     pivot block once for the whole block.  Then a Goldfarb-Idnani dual
 //     active-set on the explicit inverse, run by wave 0 out of registers
 //     (lane = variable / stance foot-step / working-set slot) with the
-//     projected inverse kept as a sum of rank-1 events (no in-place updates, no
-//     barrier in the loop).  Swing feet are eliminated up front exactly like
+//     projected inverse kept as a sum of rank-1 events (no in-place updates; no
+//     barrier in the loop in class 1 -- in the larger classes waves 1..3 take a
+//     share of the stored events once there are many).  A robot whose on-chip event
+//     pool fills up continues on a slice of an overflow pool in global memory; the
+//     Schur-form engine (second solve_one instantiation) is the last resort when the
+//     working-set slots run out.  Swing feet are eliminated up front exactly like
 //     SolverMPC.cpp:441-525.
 //   * fp64 throughout the solve (the reference hands fp32-assembled data to a
 //     double-precision qpOASES; fp64 assembly removes the fp32 rounding noise
 //     instead of adding a second, uncorrelated copy of it).
+//   * size classes chain 1 -> 4 -> 2 -> 3: the first is launched over the batch, a robot that does not fit appends
+//     itself to a work list that the next class (LISTED instantiation) consumes as a queue.
 //   * variants of the same template (own instantiations, the default kernel carries none of them):
 //     WARM  -- warm start across MPC cycles from the previous working set (qmpc_set_warm_start);
 //     ADMM  -- the reference's JCQP alternate, QpProblem::runFromDense (src/JCQP/QpProblem.cpp:178-269):
@@ -275,8 +281,8 @@ struct Cfg {
   static constexpr int CW = NP / 4;
   static constexpr int NT = 4 * NP;
   static constexpr int RE = (NP + 63) / 64;  // 64-row blocks of an index-major engine vector
-  // working-set slots: every n_r <= 64 problem fits 64; in the largest class the
-  // 160 KiB of LDS next to the packed inverse set the bound at run time (48 slots at
+  // Schur-form engine (the fallback): working-set slots.  Every n_r <= 64 problem fits 64; in the largest
+  // class the 160 KiB of LDS next to the packed inverse set the bound at run time (48 slots at
   // n_r = 192, all 96 at n_r <= 168)
   static constexpr int KMAX = (RB == 1) ? 64 : 96;
   static constexpr int KW = (KMAX + 63) / 64;  // slots per engine lane
@@ -291,7 +297,8 @@ struct Cfg {
   static constexpr int KS = (RB == 1) ? 32 : (RB == 3 ? 128 : 64);  // event-form engine: working-set slot capacity (class 3: two per lane)
   static constexpr bool EVENT_ENGINE = true;
   // class 3 has no LDS left for events: its event pool lives in global memory (one slice per workgroup in
-  // flight, L2-resident: 96 events x 2 KB), the LDS pool only serves the Schur-form fallback
+  // flight, L2-resident: 2.5 KB per event), the LDS pool only serves the helper waves' partial sums and the
+  // Schur-form fallback
   static constexpr bool GLOBAL_EVENTS = (RB == 3);
   // events a slice of a global pool holds.  Class 3's own pool: its 128 working-set slots plus room for drop events
   // before a compaction (QMPC_EV_SLICE3); the overflow pool of the other classes (at most 64 slots): QMPC_OV_SLICE
@@ -2476,8 +2483,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 
 }  // namespace
 
-// one robot with the engine pair of its class: projected-inverse engine first; the (rare) robot that runs
-// out of pool is solved again from scratch with the Schur-form engine, which cannot overflow
+// one robot with the engine pair of its class: event-form engine first (it continues in global memory when its
+// on-chip pool fills up); the (rare) robot that runs out of working-set SLOTS there is solved again from scratch
+// with the Schur-form engine, which has more of them
 template <int RB, bool CMD, bool WARM>
 __device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<RB>& S, const QmpcParams& P) {
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
