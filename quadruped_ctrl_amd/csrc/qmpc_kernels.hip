@@ -1068,13 +1068,20 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           const double c0i = cb0[i], c1i = cb1[i];
           const double i11 = pv[0], i01 = pv[1], i00 = pv[2];  // +-entries of P^-1
           notpd |= (pv[3] != 0.0);
-          // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
-          const double fg0 = __builtin_fma(i11, c0i, -i01 * c1i);
-          const double fg1 = __builtin_fma(i00, c1i, -i01 * c0i);
+          // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i ; kept NEGATED (the
+          // update is a += c * (-F): the sign goes into the fma instead of into extra instructions)
+          const double nf0 = __builtin_fma(-i11, c0i, i01 * c1i);
+          const double nf1 = __builtin_fma(-i00, c1i, i01 * c0i);
           const bool p0 = (i == k0), p1 = (i == k1);
-          // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
-          const double u0 = fg0 + (p0 ? -i11 : (p1 ? i01 : 0.0));
-          const double u1 = fg1 + (p0 ? i01 : (p1 ? -i00 : 0.0));
+          // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j).  Two lanes of ONE
+          // wave: a branch the other waves skip, instead of eight selects in every lane of every wave (the step is
+          // bound by VALU issue: ~55 of its ~105 vector instructions per wave were not the fmacs)
+          double nu0 = nf0, nu1 = nf1;
+          if (p0 | p1) {
+            asm volatile("" ::: "memory");  // (keeps the block a branch: it would be if-converted into selects)
+            nu0 = nf0 + (p0 ? i11 : -i01);
+            nu1 = nf1 + (p0 ? -i01 : i00);
+          }
           // the CW pivot-column values of this column group, 16 per register (one per
           // lane of a row), broadcast inside the DPP fmac -- see fmac16_rowbcast
           auto upd16 = [&](auto gc) __attribute__((always_inline)) {
@@ -1082,16 +1089,16 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             const double cv0 = cb0[c * CW + 16 * g + (lane & 15)];
             const double cv1 = cb1[c * CW + 16 * g + (lane & 15)];
             double(&ag)[16] = *reinterpret_cast<double(*)[16]>(&a[16 * g]);
-            fmac16_rowbcast(ag, cv0, -u0);
-            fmac16_rowbcast(ag, cv1, -u1);
+            fmac16_rowbcast(ag, cv0, nu0);
+            fmac16_rowbcast(ag, cv1, nu1);
           };
           auto upd8 = [&]() __attribute__((always_inline)) {  // class 4: the last eight columns of the group
             constexpr int G8 = CW - 8;
             const double cv0 = cb0[c * CW + G8 + (lane & 7)];
             const double cv1 = cb1[c * CW + G8 + (lane & 7)];
             double(&ag)[8] = *reinterpret_cast<double(*)[8]>(&a[G8]);
-            fmac8_rowbcast(ag, cv0, -u0);
-            fmac8_rowbcast(ag, cv1, -u1);
+            fmac8_rowbcast(ag, cv0, nu0);
+            fmac8_rowbcast(ag, cv1, nu1);
           };
           // The sixteen (eight) columns that hold the NEXT pivot pair go first: their owner publishes the pair and
           // the inverse of its 2x2 block while everybody, itself included, still updates the other columns -- the
@@ -1116,8 +1123,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if constexpr (TAIL8 && !NEXT_IN_TAIL) upd8();
           if (c == kb) {
             // pivot columns <- F, pivot block <- -P^-1
-            a[r0] = p0 ? -i11 : (p1 ? i01 : fg0);
-            a[r1] = p0 ? i01 : (p1 ? -i00 : fg1);
+            a[r0] = -nf0;
+            a[r1] = -nf1;
+            if (p0 | p1) {
+              asm volatile("" ::: "memory");
+              a[r0] = p0 ? -i11 : i01;
+              a[r1] = p0 ? i01 : -i00;
+            }
           }
           __syncthreads();
         }
