@@ -1,0 +1,46 @@
+"""CPU suite: compile-time budgets of the solve kernels (hipcc cross-compiles gfx950 without a GPU).
+
+The occupancy the design relies on is a property of the compiled code, not of the source: four 64-row workgroups
+per CU need <= 128 VGPRs and no scratch, two 96-row workgroups (6 waves each) need <= 128 VGPRs too -- at 137 only one
+fits and the class is 45 % slower, which no functional test notices."""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SRC = os.path.join(ROOT, "quadruped_ctrl_amd", "csrc", "qmpc_kernels.hip")
+
+
+def _resources(rb, tmp):
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", f"-DQMPC_RB={rb}", "-c", SRC,
+                          "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(tmp, f"k{rb}.o")],
+                         capture_output=True, text=True, check=True).stderr
+    res, name = {}, None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            res[name] = {}
+        for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                res[name][key] = int(m.group(1))
+    return res
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="no hipcc")
+def test_kernel_register_budgets(tmp_path):
+    with ThreadPoolExecutor(2) as ex:
+        r1, r4 = ex.map(lambda rb: _resources(rb, str(tmp_path)), (1, 4))
+    solve1 = {k: v for k, v in r1.items() if "qmpc_solve_kernel" in k}
+    solve4 = {k: v for k, v in r4.items() if "qmpc_solve_kernel" in k}
+    assert len(solve1) == 3 and len(solve4) == 6          # record / command / warm (x list-consuming for class 4)
+    for k, v in {**solve1, **solve4}.items():
+        warm = "ELb1ELb0EEv" in k or "ELb1ELb1EEv" in k    # <RB, CMD, WARM, LISTED>: the optional warm-start instantiations
+        assert v["scratch"] <= (32 if warm else 0), (k, v)
+        assert v["vgpr"] <= 128, (k, v)                    # 4 waves per SIMD: 4 (class 1) / 2 (class 4) workgroups per CU
