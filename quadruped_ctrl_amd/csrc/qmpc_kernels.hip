@@ -825,15 +825,37 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     // of the columns is compile-time once the start axis (wave-uniform) is fixed.
     auto fill = [&](auto cax0c) __attribute__((always_inline)) {
       constexpr int CAX0 = decltype(cax0c)::value;
+      if constexpr (RB == 3) {
 #pragma unroll
-      for (int jj = 0; jj < CW; ++jj) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int kj = kj_at((CAX0 + jj) / 3), cax = (CAX0 + jj) % 3;
-        const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + cax;
-        // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
-        a[jj] = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
-        if ((jj & (RB == 3 ? 1 : 3)) == (RB == 3 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+        for (int jj = 0; jj < CW; ++jj) {
+          const int kj = kj_at((CAX0 + jj) / 3), cax = (CAX0 + jj) % 3;
+          const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + cax;
+          // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
+          a[jj] = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
+          if ((jj & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+        }
+      } else {
+        // the table entries tau, sigma depend on the column's FOOT-STEP only: one pair of loads per stance slot
+        // the thread's columns walk, not per column (the stage is bound by LDS bytes: 64 -> 46 doubles per thread
+        // at CW = 16); same products, same sums
+        constexpr int NS = (CAX0 + CW - 1) / 3 + 1;  // slots touched
+        double t0[NS], t4[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int cidx = si * h + (kj_at(q) >> 2);
+          t0[q] = Aa.ct0[cidx];
+          t4[q] = Aa.ct4[cidx];
+        }
+#pragma unroll
+        for (int jj = 0; jj < CW; ++jj) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int q = (CAX0 + jj) / 3, cax = (CAX0 + jj) % 3;
+          const int eidx = u * 12 + 3 * (kj_at(q) & 3) + cax;
+          // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
+          a[jj] = t0[q] * Aa.E00[eidx] + t4[q] * Aa.E11[eidx];
+          if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
+        }
       }
       if (drag) {  // uniform
         // E_01 / E_12 couple (z of foot-step i, x of foot-step j); E_10 / E_21 the
