@@ -75,9 +75,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(b, spec, budget_s=8.0, all_cores=True):
+def cpu_baseline(b, spec, budget_s=8.0, all_cores=True, gpu_grf=None):
     """Reference-style CPU pipeline, bounded sample: one host core in-process, then one worker
-    process per host core (oracle/cpu_worker.py)."""
+    process per host core (oracle/cpu_worker.py).  gpu_grf: the GPU's first-step forces of the same
+    robots -- the oracle's answers on the sample double as the run's parity check (`parity_sample`:
+    max relative GRF error and the fraction of robots over north_star's 1e-4)."""
     try:
         from oracle import oracle
         if not oracle.have_ref():
@@ -85,8 +87,20 @@ def cpu_baseline(b, spec, budget_s=8.0, all_cores=True):
         n = min(b["batch"], 1024)
         arr = oracle.pack_updates(b, range(n))
         t0 = time.perf_counter()
-        oracle.solve_packed(arr, b)            # also the probe for the rate
+        first = oracle.solve_packed(arr, b)    # also the probe for the rate
         t1 = time.perf_counter() - t0
+        parity = None
+        try:
+            q_ref = np.asarray(first[0] if isinstance(first, tuple) else first, dtype=np.float64)[:n, :12]
+            if gpu_grf is not None:
+                err = np.abs(gpu_grf[:n].astype(np.float64) - q_ref).max(1) / np.maximum(np.abs(q_ref).max(1), 1.0)
+                parity = {"robots": int(n), "max_rel_grf_err": float(err.max()), "median_rel_grf_err": float(np.median(err)),
+                          "frac_over_1e-4": float((err > 1e-4).mean()),
+                          "note": "first-step GRF of the GPU vs the oracle pipeline (float assembly restatement + the "
+                                  "reference's qpOASES) on the CPU-baseline sample; beyond h = 10 the reference's own float "
+                                  "evaluation-order spread exceeds 1e-4 on some robots (tests/golden/noise_floor.json)"}
+        except Exception as e:
+            parity = {"error": repr(e)}
         reps = max(1, int(budget_s / max(t1, 1e-6)) - 1)
         reps = min(reps, 50)
         t0 = time.perf_counter()
@@ -94,7 +108,7 @@ def cpu_baseline(b, spec, budget_s=8.0, all_cores=True):
             oracle.solve_packed(arr, b)
         dt = time.perf_counter() - t0
         res = {"value": n * reps / dt, "unit": "QP solves/s", "cores": 1, "kind": "port",
-               "cpu_model": cpu_model(),
+               "cpu_model": cpu_model(), "parity_sample": parity,
                "sample": f"{reps}x first {n} robots of the workload; C restatement of "
                          f"SolverMPC.cpp assembly (fp32 dense) + the reference's own "
                          f"qpOASES 3.2.0 build (oracle/_ref), single thread, {dt:.1f} s of CPU time"}
@@ -314,8 +328,42 @@ def main():
                              "contract fields above are the single-stream run"}
         mpc2.close()
 
+    # ---- extra for N > 1 (always, not only with --gather): the same K steps once more with ONE RCCL
+    # all_gather_into_tensor of the 48-byte grf rows per step, so that the driver's default N-rank command
+    # exercises an RCCL data collective and its cost is visible next to the collective-free contract number
+    gather_obj = None
+    if dist is not None:
+        g_all = gathered if gathered is not None else torch.empty((world * per_gpu, 12), dtype=torch.float32, device=f"cuda:{dev}")
+
+        def step_gather():
+            mpc.solve_async(per_gpu, inp, out, stream)
+            dist.all_gather_into_tensor(g_all, o["grf"])
+        for _ in range(max(args.warmup, 2)):
+            step_gather()
+        sync_all()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            step_gather()
+        sync_all()
+        tg = time.perf_counter() - tg
+        t = torch.tensor([tg], dtype=torch.float64, device=f"cuda:{dev}")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        tg_max = max(float(x.item()) for x in allt)
+        ok = bool(torch.equal(g_all[rank * per_gpu:(rank + 1) * per_gpu], o["grf"]))
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{dev}")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        gather_obj = {"collective": "all_gather_into_tensor (RCCL over xGMI)" if os.environ.get("QMPC_BENCH_BACKEND", "nccl") == "nccl"
+                      else "all_gather_into_tensor (gloo dry run)",
+                      "bytes_per_step": int(world * per_gpu * 48), "value": per_gpu * world * args.steps / tg_max,
+                      "unit": "QP solves/s", "ms_per_step": tg_max / args.steps * 1e3,
+                      "gathered_rows_match_local_on_every_rank": bool(int(okt.item()) == 1),
+                      "note": "K steps, each followed by one all-gather of every rank's grf[shard][12] rows (max over ranks); "
+                              "the contract fields are the collective-free run unless --gather was given"}
+
     status = o["status"].cpu().numpy()
     iters = o["iters"].cpu().numpy()
+    grf_host = o["grf"].cpu().numpy()
     nst = ((rec["gait"].cpu().numpy() if args.caller_side else b["gait"]) != 0).sum(1)
     n_fail = int(((status & 47) != 0).sum())   # QMPC_ST_ERROR_MASK
     gather_ok = None
@@ -333,6 +381,7 @@ def main():
         # counters of the last PMC run (tools/pmc.sh -> tools/pmc_to_latest.py), valid only for the
         # kernel source they were collected on
         traffic = executed = None
+        pmc_extra = {}
         pmc_note = "no PMC entry for this workload in profiles/pmc_latest.json"
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -342,6 +391,9 @@ def main():
                     if ent.get("kernel_source_sha") == kernel_source_hash():
                         traffic = ent.get("hbm_bytes_per_launch")
                         executed = ent.get("fp64_flops_per_launch")
+                        pmc_extra = {"lds_bank_conflict_rate": ent.get("lds_bank_conflict_rate"),
+                                     "wave_cycle_shares": ent.get("wave_cycle_shares"),
+                                     "rocprof": ent.get("rocprof"), "pmc_profile": ent.get("profile")}
                         pmc_note = f"PMC counters from {ent.get('profile')} (same kernel source)"
                     else:
                         pmc_note = "profiles/pmc_latest.json was collected on a different kernel source: dropped"
@@ -372,19 +424,26 @@ def main():
             # The path is compute-shaped, not HBM-shaped: the binding roof is the fp64
             # VALU rate.  The kernel issues vector fp64 (DPP fmac), no MFMA; on MI355X the dense fp64
             # MFMA peak is the same 78.6 TFLOP/s.
-            "roofline": {"bound": "fp64_valu", "achieved": flops / t_s / 1e12,
+            "roofline": dict({"bound": "fp64_valu",
+                         # primary figure: what the kernel EXECUTES (fp64 wave-instructions from the PMC counters of this
+                         # kernel source) over the HIP-event time; without counters for this source: the SURVEY 8d figure
+                         "achieved": (executed if executed else flops) / t_s / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / t_s / 1e12 / FP64_PEAK_TFLOPS,
+                         "frac": (executed if executed else flops) / t_s / 1e12 / FP64_PEAK_TFLOPS,
+                         "frac_is": "executed" if executed else "reference_equivalent (no PMC counters for this kernel source)",
                          "traffic": traffic,
                          "kernel": kname, "kernel_ms_hip_events": step_ms_ev,
-                         "alg_flops_per_qp": flops / per_gpu,
                          "executed_flops_per_qp": (executed / per_gpu if executed else None),
                          "executed_tflops": (executed / t_s / 1e12 if executed else None),
                          "executed_frac": (executed / t_s / 1e12 / FP64_PEAK_TFLOPS if executed else None),
-                         "note": "achieved/frac: algorithmic (reference-equivalent) fp64 flops F_alg(h, n_r, K) of "
-                                 "SURVEY.md 8d over the HIP-event kernel time; the closed-form assembly does not "
-                                 "execute F_cond, so executed_* (64 lanes x (2 FMA + MUL + ADD) fp64 wave-instructions, "
-                                 "PMC) is the honest utilisation figure. " + pmc_note},
+                         # SURVEY.md 8d's ALGORITHMIC flops F_alg(h, n_r, K) -- what the reference's dense formulation needs
+                         "reference_equivalent_flops_per_qp": flops / per_gpu,
+                         "reference_equivalent_tflops": flops / t_s / 1e12,
+                         "reference_equivalent_frac": flops / t_s / 1e12 / FP64_PEAK_TFLOPS,
+                         "note": "frac = executed fp64 flops (64 lanes x (2 FMA + MUL + ADD) wave-instructions, PMC) over the "
+                                 "HIP-event kernel time against the 78.6 TFLOP/s fp64 peak; reference_equivalent_*: SURVEY.md 8d's "
+                                 "algorithmic F_alg(h, n_r, K), 84 % of which is the dense condensation the closed-form assembly "
+                                 "never executes. " + pmc_note}, **pmc_extra),
             "roofline_hbm": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                              "alg_bytes_per_qp": alg_bytes_per_qp(h),
@@ -394,10 +453,17 @@ def main():
             res["per_rank"] = {"elapsed_s": per_rank,
                                "qp_per_s": [per_gpu * args.steps / t for t in per_rank],
                                "gathered_rows_match_local": gather_ok}
+        if gather_obj is not None:
+            res["gather"] = gather_obj
         if pipelined is not None:
             res["pipelined"] = pipelined
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(b, spec, all_cores=not args.no_cpu_all_cores)
+            res["cpu_baseline"] = cpu_baseline(b, spec, all_cores=not args.no_cpu_all_cores,
+                                               gpu_grf=None if args.caller_side else grf_host)
+            ps = (res["cpu_baseline"] or {}).get("parity_sample")
+            if ps and "max_rel_grf_err" in ps:
+                # the fraction of robots over north_star's flat 1e-4 and the maximum, next to the workload they belong to
+                res["config"]["parity_sample"] = {k: ps[k] for k in ("robots", "max_rel_grf_err", "frac_over_1e-4")}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

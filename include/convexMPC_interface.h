@@ -48,10 +48,16 @@ QMPC_C_LINKAGE void update_problem_data_floats(float* p, float* v, float* q, flo
 void update_x_drag(float x_drag);
 #endif
 
-/* status bits (QMPC_ST_* of qmpc.h) of the most recent solve; -1 = never solved.
- * QMPC_SHIM_ST_JCQP_IGNORED is set next to them when update_solver_settings' use_jcqp is a value
- * other than 0, 1 or 2 (nothing to select: the exact solve ran). */
-#define QMPC_SHIM_ST_JCQP_IGNORED 256
+/* status of the most recent call: >= 0 = status bits (QMPC_ST_* of qmpc.h) of the most recent solve;
+ * -1 = never solved; other negative values = the call was refused and get_solution reads 0:
+ *   QMPC_SHIM_ERR_SETUP     setup_problem rejected (horizon beyond QMPC_MAX_HORIZON, mu / dt <= 0, no device)
+ *                           or update_problem_data* without an accepted setup_problem
+ *   QMPC_SHIM_ERR_SETTINGS  update_solver_settings values unusable for the selected use_jcqp (e.g. rho <= 0)
+ *   QMPC_SHIM_ERR_SOLVE     the batched solver returned an error code (see stderr)
+ * use_jcqp is thresholded like the reference (convexMPC_interface.cpp:113-118): > 1.5 -> 2, > 0.5 -> 1, else 0. */
+#define QMPC_SHIM_ERR_SETUP (-2)
+#define QMPC_SHIM_ERR_SETTINGS (-3)
+#define QMPC_SHIM_ERR_SOLVE (-4)
 QMPC_C_LINKAGE int qmpc_shim_last_status(void);
 /* active-set iterations of the most recent solve */
 QMPC_C_LINKAGE int qmpc_shim_last_iters(void);

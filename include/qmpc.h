@@ -231,6 +231,10 @@ int qmpc_set_debug_aux(qmpc_handle h, double* aux_dev);
  * global-memory records a robot continues on when its on-chip event pool is full (QMPC_ST_SPILLED); robots that find
  * no slice are re-solved by the Schur-form engine (QMPC_ST_FALLBACK).  Negative n restores the default. */
 int qmpc_set_debug_overflow_slices(qmpc_handle h, int n);
+/* Test hook: on != 0 makes every slice of the 192-row class's global event pool look taken, so that every
+ * workgroup of that class times out waiting for one: its robots must then be solved by the Schur-form engine
+ * (QMPC_ST_FALLBACK set, same answer) instead of proceeding on a slice they do not own. */
+int qmpc_set_debug_pool_busy(qmpc_handle h, int on);
 /* Profiling hook: DEVICE buffer clk[B][16] receiving shader-clock stamps at
  * the kernel's phase boundaries (NULL = off). */
 int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);
@@ -385,6 +389,8 @@ const char* qmpc_last_error(qmpc_handle h);
 
 /* Library/ABI version, bumped on any signature change. */
 int qmpc_abi_version(void);
+/* QMPC_MAX_HORIZON of the library that is loaded (for FFI callers that cannot read the macro). */
+int qmpc_max_horizon(void);
 
 #ifdef __cplusplus
 }

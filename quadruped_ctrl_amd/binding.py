@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 12              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 13              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_COMPACTED, ST_SPILLED = 64, 128
 ST_NONFINITE = 32
@@ -24,7 +24,8 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_set_debug_clock", "qmpc_set_max_stance", "qmpc_pack",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
-           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model"]
+           "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
@@ -98,6 +99,7 @@ def load_library():
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_debug_overflow_slices.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_debug_pool_busy.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.qmpc_set_model.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_kf_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -459,6 +461,9 @@ class BatchedConvexMPC:
     def debug_overflow_slices(self, n):
         """Test hook: use only n slices of the overflow event pool (negative: all)."""
         self._check(self.lib.qmpc_set_debug_overflow_slices(self.h, int(n)), "qmpc_set_debug_overflow_slices")
+
+    def set_debug_pool_busy(self, on):
+        self._check(self.lib.qmpc_set_debug_pool_busy(self.h, int(bool(on))), "qmpc_set_debug_pool_busy")
 
     def debug_clock(self, batch):
         """Enable per-phase shader-clock stamps; returns the [batch,16] tensor."""

@@ -36,7 +36,11 @@ bool ensure_handle() {
 void solve_floats(const float* p, const float* v, const float* q, const float* w, const float* r,
                   float yaw, const float* weights, const float* traj, float alpha, const int* gait) {
   if (!g.h || g.horizon <= 0) {
-    std::fprintf(stderr, "[qmpc shim] update_problem_data before setup_problem\n");
+    // no accepted setup_problem (never called, no device, or a horizon / mu / dt it refused): nothing is solved,
+    // get_solution reads 0 and the failure is visible through qmpc_shim_last_status()
+    std::fprintf(stderr, "[qmpc shim] update_problem_data without an accepted setup_problem\n");
+    g.status = QMPC_SHIM_ERR_SETUP;
+    g.has_solved = false;
     return;
   }
   const int h = g.horizon;
@@ -53,16 +57,24 @@ void solve_floats(const float* p, const float* v, const float* q, const float* w
   out.grf = grf; out.soln = g.q_soln.data(); out.status = &st; out.iters = &it;
   // use_jcqp = 1 / 2: the reference's JCQP/ADMM alternate (SolverMPC.cpp:400-414, :558-610), reproduced
   // on the GPU; otherwise the exact solve
-  const int mode = (g.use_jcqp == 1.0) ? 1 : (g.use_jcqp == 2.0 ? 2 : 0);
-  qmpc_settings_jcqp(g.h, mode, g.max_iter, g.rho, g.sigma, g.alpha, g.terminate);
-  const int rc = qmpc_solve_host(g.h, 1, &in, &out);
+  // (the double is thresholded exactly like convexMPC_interface.cpp:113-118: > 1.5 -> 2, > 0.5 -> 1, else 0)
+  const int mode = (g.use_jcqp > 1.5) ? 2 : (g.use_jcqp > 0.5 ? 1 : 0);
+  int rc = qmpc_settings_jcqp(g.h, mode, g.max_iter, g.rho, g.sigma, g.alpha, g.terminate);
   if (rc != QMPC_OK) {
-    std::fprintf(stderr, "[qmpc shim] solve failed rc=%d %s\n", rc, qmpc_last_error(g.h));
+    // e.g. rho <= 0: the reference would factor a singular KKT matrix; here the call is refused and reported
+    std::fprintf(stderr, "[qmpc shim] update_solver_settings values rejected for use_jcqp=%d (rc=%d)\n", mode, rc);
+    g.status = QMPC_SHIM_ERR_SETTINGS;
+    g.q_soln.assign(12 * h, 0.0);
     return;
   }
-  // (a use_jcqp value other than 0, 1, 2 selects nothing in the reference either -- the exact solve
-  //  runs -- and is reported)
-  g.status = st | ((g.use_jcqp != 0.0 && g.use_jcqp != 1.0 && g.use_jcqp != 2.0) ? QMPC_SHIM_ST_JCQP_IGNORED : 0);
+  rc = qmpc_solve_host(g.h, 1, &in, &out);
+  if (rc != QMPC_OK) {
+    std::fprintf(stderr, "[qmpc shim] solve failed rc=%d %s\n", rc, qmpc_last_error(g.h));
+    g.status = QMPC_SHIM_ERR_SOLVE;
+    g.q_soln.assign(12 * h, 0.0);
+    return;
+  }
+  g.status = st;
   g.iters = it;
   if (st & QMPC_ST_ERROR_MASK) std::printf("failed to solve! (status bits %d)\n", st);  // SolverMPC.cpp:541
   g.has_solved = true;
@@ -73,12 +85,17 @@ void solve_floats(const float* p, const float* v, const float* q, const float* w
 extern "C" {
 
 void setup_problem(double dt, int horizon, double mu, double f_max) {
-  if (!ensure_handle()) return;
+  if (!ensure_handle()) {
+    g.status = QMPC_SHIM_ERR_SETUP;
+    return;
+  }
   const int rc = qmpc_setup(g.h, dt, horizon, mu, f_max);
   if (rc != QMPC_OK) {
     std::fprintf(stderr, "[qmpc shim] setup_problem(dt=%g, horizon=%d, mu=%g, f_max=%g) rejected rc=%d\n",
                  dt, horizon, mu, f_max, rc);
     g.horizon = 0;
+    g.status = QMPC_SHIM_ERR_SETUP;  // loud: not only stderr (the reference accepts up to K_MAX_GAIT_SEGMENTS)
+    g.has_solved = false;            // get_solution reads 0 from now on, never a previous horizon's forces
     return;
   }
   g.horizon = horizon;

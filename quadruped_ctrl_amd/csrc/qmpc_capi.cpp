@@ -98,6 +98,7 @@ struct qmpc_ctx {
   int ov_nslice = 0;
   int* d_evflags = nullptr;
   int ev_nslot = 0;
+  bool dbg_pool_busy = false;  // test hook: every slice of the 192-row class's pool looks taken (qmpc_set_debug_pool_busy)
   int32_t* ws = nullptr;  // warm-start buffer (device), see qmpc_set_warm_start
   int ws_shift = 1;
   double* dbg_H = nullptr;
@@ -162,7 +163,8 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 12; }
+int qmpc_abi_version(void) { return 13; }
+int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -226,6 +228,19 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   c->f_max = (double)(float)f_max;
   c->horizon = horizon;
   const int h = horizon;
+  if (12 * h > 128 && !c->d_evpool) {
+    // the 192-row class keeps its rank-1 events in global memory: one 400 KiB slice (QMPC_EV_SLICE3) per workgroup in
+    // flight (256 CUs x 1 workgroup); 1024 flag-guarded slices, so that a slice's previous tenant has usually finished
+    // (a workgroup whose predecessor on its slice is still running waits for it).  Allocated here, where the
+    // horizon that makes the class reachable is announced -- never inside a solve call (a hipMalloc there
+    // synchronises the device and cannot be captured into a graph)
+    DeviceGuard g0(c->device);
+    const int nslot = c->max_batch < 1024 ? c->max_batch : 1024;
+    HIP_TRY(c, hipMalloc(&c->d_evpool, sizeof(double) * (size_t)nslot * QMPC_EV_SLICE3));
+    HIP_TRY(c, hipMalloc(&c->d_evflags, sizeof(int) * (size_t)nslot));
+    HIP_TRY(c, hipMemset(c->d_evflags, 0, sizeof(int) * (size_t)nslot));
+    c->ev_nslot = nslot;
+  }
   // the tables depend on (dt, horizon) only: the reference's caller repeats setup_problem with the
   // same values before every solve (ConvexMPCLocomotion.cpp:630), which costs nothing here
   if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h && c->tab_model == c->model) return QMPC_OK;
@@ -339,6 +354,12 @@ int qmpc_set_debug_overflow_slices(qmpc_handle c, int n) {
   const int all = c->max_batch < 1024 ? c->max_batch : 1024;  // what qmpc_create allocated
   if (n > all) return QMPC_ERR_ARG;  // more slices than allocated
   c->ov_nslice = n < 0 ? all : n;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug_pool_busy(qmpc_handle c, int on) {
+  if (!c) return QMPC_ERR_ARG;
+  c->dbg_pool_busy = on != 0;
   return QMPC_OK;
 }
 
@@ -462,21 +483,12 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       if (nb <= rows[k]) { hc = k + 1; break; }
     if (hc < nclass_eff) nclass_eff = hc;
   }
-  if (nclass_eff == 4 && !c->d_evpool) {
-    // the 192-row class keeps its rank-1 events in global memory: one 400 KiB slice (QMPC_EV_SLICE3) per workgroup in
-    // flight (256 CUs x 1 workgroup); 1024 flag-guarded slices, so that a slice's previous tenant has usually finished
-    // (a workgroup whose predecessor on its slice is still running waits for it)
-    const int nslot = c->max_batch < 1024 ? c->max_batch : 1024;
-    HIP_TRY(c, hipMalloc(&c->d_evpool, sizeof(double) * (size_t)nslot * QMPC_EV_SLICE3));
-    HIP_TRY(c, hipMalloc(&c->d_evflags, sizeof(int) * (size_t)nslot));
-    HIP_TRY(c, hipMemset(c->d_evflags, 0, sizeof(int) * (size_t)nslot));
-    c->ev_nslot = nslot;
-  }
   P.ovpool = c->d_ovpool;
   P.ov_nslice = c->ov_nslice;
   P.evpool = c->d_evpool;
   P.evflags = c->d_evflags;
   P.ev_nslot = c->ev_nslot;
+  P.ev_spin = c->dbg_pool_busy ? 4 : (1 << 16);
   const unsigned set = c->call_no & 1u;
   c->call_no++;
   int* cnt = c->d_counts + 8 * set;             // this call's counters (one per list)
@@ -494,7 +506,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;
     if (chain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
-      HIP_TRY(c, hipMemsetAsync(c->d_evflags, 0, sizeof(int) * (size_t)c->ev_nslot, stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_evflags, c->dbg_pool_busy ? 1 : 0, sizeof(int) * (size_t)c->ev_nslot, stream));
     // the first class of the chain: one workgroup per robot; the later ones: one per resident slot, the list
     // is consumed as a queue (no workgroup is dispatched only to find its list entry missing)
     int grid = batch;

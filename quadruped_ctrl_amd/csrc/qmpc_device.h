@@ -70,6 +70,7 @@ struct QmpcParams {
   double* evpool;
   int* evflags;
   int ev_nslot;
+  int ev_spin;  // bound of the wait for a slice's previous tenant (a workgroup that times out runs the Schur form)
   // classes 1, 4, 2: overflow pool in global memory for the robot whose LDS event pool is full: ov_nslice slices of
   // QMPC_OV_SLICE doubles, handed out by the counter *ov_count (one per robot and launch chain; nullptr = none)
   double* ovpool;

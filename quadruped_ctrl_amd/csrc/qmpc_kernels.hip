@@ -2523,7 +2523,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 template <int RB, bool CMD, bool WARM>
 __device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<RB>& S, const QmpcParams& P) {
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
-    const bool again = solve_one<RB, true, CMD, false, WARM>(rid, tid, S, P);
+    bool again;
+    if (Cfg<RB>::GLOBAL_EVENTS && S.evslot < 0) again = true;  // no pool slice (pool_acquire timed out): Schur form only
+    else again = solve_one<RB, true, CMD, false, WARM>(rid, tid, S, P);
     if (again) {
       __syncthreads();
       // opaque thread id: without it the compiler keeps per-thread values of the
@@ -2541,16 +2543,24 @@ __device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<R
 
 // class 3: take a slice of the global event pool for the lifetime of the workgroup: slot = workgroup index
 // modulo the slice count, guarded by a flag (a workgroup whose predecessor on that slice is still running --
-// it would have to be ~ev_nslot / 256 times slower than average -- waits for it)
+// it would have to be ~ev_nslot / 256 times slower than average -- waits for it).  The wait is bounded (a flag
+// left behind by an aborted launch must not hang this one); a workgroup that does NOT get its slice never
+// touches it: S.evslot = -1, its robots are solved by the Schur-form engine (no global pool) and carry
+// QMPC_ST_FALLBACK -- slower, never silently wrong.
 template <int RB>
 __device__ __forceinline__ void pool_acquire(Smem<RB>& S, const QmpcParams& P) {
   if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
     if (threadIdx.x == 0) {
       const int slot = (int)(blockIdx.x % (unsigned)P.ev_nslot);
-      // (bounded: a flag left behind by an aborted launch must not hang this one; the host clears the flags
-      //  before every launch of this class anyway)
-      for (int spin = 0; spin < (1 << 16) && atomicCAS(&P.evflags[slot], 0, 1) != 0; ++spin) __builtin_amdgcn_s_sleep(8);
-      S.evslot = slot;
+      bool mine = false;
+      for (int spin = 0; spin < P.ev_spin; ++spin) {
+        if (atomicCAS(&P.evflags[slot], 0, 1) == 0) {
+          mine = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      S.evslot = mine ? slot : -1;
     }
     __syncthreads();
   }
@@ -2559,7 +2569,7 @@ template <int RB>
 __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
   if constexpr (Cfg<RB>::GLOBAL_EVENTS) {
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && S.evslot >= 0) {
       __threadfence();
       atomicExch(&P.evflags[S.evslot], 0);
     }

@@ -1,6 +1,5 @@
-"""PyTorch custom operators over the C ABI: `torch.ops.qmpc.solve` and
-`torch.ops.qmpc.solve_commands_like` for batched RL / simulation users who hold their robot states
-in torch tensors on the GPU.
+"""PyTorch custom operator over the C ABI: `torch.ops.qmpc.solve` for batched RL /
+simulation users who hold their robot states in torch tensors on the GPU.
 
     import quadruped_ctrl_amd.torch_op            # registers the ops
     grf, soln, status, iters = torch.ops.qmpc.solve(p, v, q, w, r, yaw, traj, gait, weights, alpha, x_drag,
@@ -11,35 +10,44 @@ qmpc_solve), the work is enqueued on torch's CURRENT stream, nothing synchronise
 the hand-written HIP kernels of libqmpc.so.  There is no CPU implementation: the op is registered for
 the "cuda" device type only, so a CPU tensor fails loudly in the dispatcher.
 
-Handles are cached per (device, horizon, dt, mu, f_max) and grown when a larger batch arrives; one
-handle serialises its calls (include/qmpc.h, "Streams"), so concurrent streams on one device are
-ordered, not raced.
+Handles are cached per (device, horizon, dt) -- what the handle's tables depend on; mu and f_max are
+plain parameters of the next launch, so sweeping them (domain randomisation) reuses ONE handle -- and
+grown when a larger batch arrives.  The cache holds at most MAX_HANDLES entries (least recently used
+is destroyed: a handle owns a few hundred MB of event pools).  One handle serialises its calls
+(include/qmpc.h, "Streams"), so concurrent streams on one device are ordered, not raced.
 """
+from collections import OrderedDict
 import ctypes as C
 
 import torch
 
 from . import binding as _b
 
-_handles = {}
+_handles = OrderedDict()
+MAX_HANDLES = 4
 
 
 def _solver(device, horizon, dt, mu, f_max, batch):
-    key = (device.index, int(horizon), float(dt), float(mu), float(f_max))
+    key = (device.index, int(horizon), float(dt))
     ent = _handles.get(key)
     if ent is None or ent[1] < batch:
         if ent is not None:
             ent[0].close()
         cap = max(int(batch), 1024)
         m = _b.BatchedConvexMPC(device.index, max_batch=cap, max_horizon=_b_max_horizon())
-        m.setup(dt, horizon, mu, f_max)
         ent = (m, cap)
         _handles[key] = ent
+        while len(_handles) > MAX_HANDLES:            # least recently used first
+            _, (old, _cap) = _handles.popitem(last=False)
+            old.close()
+    _handles.move_to_end(key)
+    # qmpc_setup returns at once when (dt, horizon) are unchanged: mu / f_max only update the parameter block
+    ent[0].setup(dt, horizon, mu, f_max)
     return ent[0]
 
 
 def _b_max_horizon():
-    return 16   # QMPC_MAX_HORIZON
+    return int(_b.load_library().qmpc_max_horizon())
 
 
 def _chk(t, name, dtype, shape):
@@ -65,8 +73,13 @@ def solve(p: torch.Tensor, v: torch.Tensor, q: torch.Tensor, w: torch.Tensor, r:
     _chk(p, "p", f32, (B, 3)); _chk(v, "v", f32, (B, 3)); _chk(q, "q", f32, (B, 4)); _chk(w, "w", f32, (B, 3))
     _chk(r, "r", f32, (B, 12)); _chk(yaw, "yaw", f32, (B,)); _chk(traj, "traj", f32, (B, 12 * h))
     _chk(gait, "gait", torch.uint8, (B, 4 * h))
-    if weights.dtype != f32 or weights.numel() not in (12, 12 * B) or alpha.numel() not in (1, B) or x_drag.numel() not in (1, B):
-        raise ValueError("qmpc::solve: weights [B,12] or [12]; alpha, x_drag [B] or [1] (float32)")
+    for name, t, sizes in (("weights", weights, (12, 12 * B)), ("alpha", alpha, (1, B)), ("x_drag", x_drag, (1, B))):
+        # (a float64 tensor, e.g. one built from numpy, would be reinterpreted as float32 by the kernel)
+        if t.dtype != f32 or t.numel() not in sizes or t.device != p.device:
+            raise ValueError(f"qmpc::solve: {name} must be float32 on {p.device} with {sizes[0]} or {sizes[1]} elements "
+                             f"(weights [B,12] or [12]; alpha, x_drag [B] or [1]), got {t.dtype} {tuple(t.shape)} on {t.device}")
+    if weights.numel() == 12 * B and B > 1 and tuple(weights.shape) != (B, 12):
+        raise ValueError(f"qmpc::solve: per-robot weights must have shape {(B, 12)}, got {tuple(weights.shape)}")
     dev = p.device
     m = _solver(dev, h, dt, mu, f_max, B)
     grf = torch.empty((B, 12), dtype=f32, device=dev)

@@ -69,6 +69,10 @@ def measure(b):
         # (>= its distance to the default order that the goldens hold)
         "per_robot_first_step": [float("%.3e" % x) for x in col["fp64_12"]],
         "per_robot_full": [float("%.3e" % x) for x in col["fp64_full"]],
+        # per robot: pairwise spread of the six FLOAT orders alone (no fp64 term) -- the bound the h > 10
+        # parity tests use: it is measured on the reference pipeline only, so it says nothing about the GPU
+        "per_robot_spread_first_step": [float("%.3e" % x) for x in col["spread12"]],
+        "per_robot_spread_full": [float("%.3e" % x) for x in col["spread_full"]],
     }
 
 

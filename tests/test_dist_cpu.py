@@ -18,17 +18,25 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, use_gpu=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from quadruped_ctrl_amd import workloads as W
-    from oracle import oracle as O
     full = W.make_config(2, batch=10)
     mine = W.shard(full, rank, world)
-    # stand-in for the GPU solve in this CPU test: the checker itself
-    q, nwsr, rc = O.solve_batch(mine)
+    if use_gpu:
+        # the product: one handle per rank (the ranks share this box's GPU), the real HIP solver
+        from quadruped_ctrl_amd.binding import BatchedConvexMPC
+        m = BatchedConvexMPC(0, max_batch=mine["batch"], max_horizon=16)
+        m.setup(mine["dt"], mine["horizon"], mine["mu"], mine["f_max"])
+        q = m.solve(mine, full=True)["soln"]
+        m.close()
+    else:
+        # stand-in for the GPU solve in the CPU suite: the checker itself
+        from oracle import oracle as O
+        q, nwsr, rc = O.solve_batch(mine)
     # the only collectives of the bench: barrier + MAX of elapsed + size gather
     dist.barrier()
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
@@ -61,3 +69,29 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     assert parts[0]["sizes"].tolist() == [5, 5]
     for p in parts:       # every rank holds the single-process result after the gather
         assert np.array_equal(p["gathered"], qref[:, :12].astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_two_rank_sharding_real_solver(tmp_path):
+    """The same two-rank plumbing with the PRODUCT on every rank: each rank solves its shard with
+    the HIP solver, the all-gather collects the forces; the union equals a single-process solve of the whole batch bit
+    for bit, and the oracle within north_star's tolerance."""
+    from oracle import oracle as O
+    from quadruped_ctrl_amd import workloads as W
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
+    full = W.make_config(2, batch=10)
+    m = BatchedConvexMPC(0, max_batch=10, max_horizon=16)
+    m.setup(full["dt"], full["horizon"], full["mu"], full["f_max"])
+    single = m.solve(full, full=True)["soln"]
+    m.close()
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert np.array_equal(np.concatenate([p["q"] for p in parts]), single)
+    for p in parts:
+        assert np.array_equal(p["gathered"], single[:, :12].astype(np.float32))
+    qref, _, rc = O.solve_batch(full)
+    assert (rc == 0).all()
+    err = np.abs(single[:, :12] - qref[:, :12]).max(1) / np.maximum(np.abs(qref[:, :12]).max(1), 1.0)
+    assert err.max() < 1e-4

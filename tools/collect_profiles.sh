@@ -38,7 +38,7 @@ PY
 rm -f profiles/pmc_latest.json
 for pair in "cfg1 config1 1024" "standing_h10 standing_h10 1024" "standing_h14 standing_h14 1024" "standing_h16 standing_h16 1024" "trot_h16 config3 4096"; do
   set -- $pair
-  python tools/pmc_to_latest.py profiles/${T}_pmc_summary_$1.json $2 $3 profiles/${T}_pmc_summary_$1.json > /dev/null
+  python tools/pmc_to_latest.py profiles/${T}_pmc_summary_$1.json $2 $3 profiles/${T}_pmc_summary_$1.json profiles/${T}_kernel_stats_$1.csv > /dev/null
 done
 python -c "
 import json; d=json.load(open('profiles/pmc_latest.json')); [print(k, int(v['hbm_bytes_per_launch']), '%.3g'%v['fp64_flops_per_launch'], v['kernel_source_sha'], {a:round(b,2) for a,b in v['wave_cycle_shares'].items()}) for k,v in d.items()]"

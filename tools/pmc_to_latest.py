@@ -1,9 +1,12 @@
 """Fold a tools/pmc.sh run into profiles/pmc_latest.json (what bench.py's roofline.traffic and
 roofline.executed_* read), stamped with the hash of the kernel source it was collected on.
 
-    python tools/pmc_to_latest.py <pmc_summary.json | its directory> <workload-key> <batch> <profile-name>
-e.g. python tools/pmc_to_latest.py gpurun_out/r02_pmc_cfg1 config1 1024 profiles/r02_a_pmc_summary.json
+    python tools/pmc_to_latest.py <pmc_summary.json | its directory> <workload-key> <batch> <profile-name> [kernel_stats.csv]
+e.g. python tools/pmc_to_latest.py gpurun_out/r02_pmc_cfg1 config1 1024 profiles/r02_a_pmc_summary.json profiles/r02_a_kernel_stats.csv
+(the optional rocprofv3 --kernel-trace --stats csv of the same command: the dominant kernel's average duration is
+recorded next to the counters, with the file name, so that the bench line can cite it)
 """
+import csv
 import json
 import os
 import sys
@@ -31,5 +34,16 @@ latest[key] = {
     "wave_cycle_shares": {k: (d.get(k, 0.0) / d["SQ_WAVE_CYCLES"] if d.get("SQ_WAVE_CYCLES") else None)
                           for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")},
 }
+ent = latest[key]
+# LDS bank-conflict rate of the solver kernel = conflict cycles / LDS-active cycles
+ent["lds_bank_conflict_rate"] = (d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]
+                                 if d.get("SQ_LDS_IDX_ACTIVE") else None)
+if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+    rows = [r for r in csv.DictReader(open(sys.argv[5])) if "qmpc_" in r["Name"]]
+    if rows:
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        ent["rocprof"] = {"file": os.path.relpath(sys.argv[5], ROOT) if os.path.isabs(sys.argv[5]) else sys.argv[5],
+                          "kernel": top["Name"], "calls": int(top["Calls"]), "avg_us": float(top["AverageNs"]) / 1e3,
+                          "all_qmpc_kernels_avg_us": {r["Name"]: float(r["AverageNs"]) / 1e3 for r in rows}}
 json.dump(latest, open(path, "w"), indent=1)
 print(json.dumps(latest[key], indent=1))
