@@ -41,7 +41,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64 (= dense FP64 MFMA peak)
-KERNEL_SOURCES = ["quadruped_ctrl_amd/csrc/qmpc_kernels.hip", "quadruped_ctrl_amd/csrc/qmpc_cmd.h",
+KERNEL_SOURCES = ["quadruped_ctrl_amd/csrc/qmpc_kernels.hip", "quadruped_ctrl_amd/csrc/qmpc_engine.hip",
+                  "quadruped_ctrl_amd/csrc/qmpc_wave.h", "quadruped_ctrl_amd/csrc/qmpc_cmd.h",
                   "quadruped_ctrl_amd/csrc/qmpc_device.h"]
 
 

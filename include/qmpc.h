@@ -63,9 +63,10 @@ extern "C" {
 #define QMPC_ST_INFEASIBLE 4 /* constraints inconsistent (cannot happen for
                                 friction pyramids with f_max >= 0) */
 #define QMPC_ST_WS_FULL 8    /* working-set capacity exceeded */
-#define QMPC_ST_FALLBACK 16  /* informational, NOT an error: the robot was solved by the
-                                slower Schur-form engine because the fast engine's
-                                working-set pool was exhausted */
+#define QMPC_ST_FALLBACK 16  /* informational, NOT an error: the robot was solved by a slower engine than
+                                its class's first choice: the Schur-form engine (the fast engine's working-set
+                                slots were exhausted), or the one-kernel path after the decoupled path's engine
+                                kernel handed it back (more rank-1 events than its registers hold) */
 #define QMPC_ST_NONFINITE 32 /* the result contains NaN / Inf (non-finite input) */
 #define QMPC_ST_COMPACTED 64 /* informational, NOT an error: the fast engine ran out of pool with
                                 constraints that had entered and left the working set again, and
@@ -174,6 +175,19 @@ int qmpc_set_max_stance(qmpc_handle h, int max_stance_footsteps);
  * A robot below the bound is still solved correctly.  0 = no hint. */
 int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 
+/* Decoupled path of the 128- and 192-row size classes (n_r > 96: all four feet down, dense random contact tables).
+ * on (default): the robot's condensed Hessian is inverted by a sweep kernel that leaves the inverse in a work item
+ * in global memory (128 / 288 KiB per robot of the largest batch, allocated when a call first reaches the class or
+ * by qmpc_reserve), and the active set is run by a second kernel, one robot per small workgroup with the rank-1
+ * events of the method in the register file of helper waves -- instead of one workgroup pinning a whole CU for the
+ * whole solve.  Same unique minimiser; a robot that outgrows the engine's registers is re-solved by the
+ * one-kernel path.  off: the one-kernel path for every class (QMPC_NO_SPLIT=1 in the environment selects that
+ * at qmpc_create).  The JCQP alternate and warm-started solves always take the one-kernel path. */
+int qmpc_set_split(qmpc_handle h, int on);
+/* Allocate now whatever the current setup and stance hints can need later (the decoupled path's work items), so
+ * that no solve call allocates -- call it before capturing solves into a graph. */
+int qmpc_reserve(qmpc_handle h);
+
 /* Warm start across MPC cycles (the reference cold-starts every solve,
  * SolverMPC.cpp:529-541).  ws_dev[max_batch][QMPC_WS_SLOTS] is a DEVICE buffer the caller keeps
  * between cycles, initialised to -1.  While it is set, every solve (a) reads robot b's previous
@@ -231,6 +245,9 @@ int qmpc_set_debug_aux(qmpc_handle h, double* aux_dev);
  * global-memory records a robot continues on when its on-chip event pool is full (QMPC_ST_SPILLED); robots that find
  * no slice are re-solved by the Schur-form engine (QMPC_ST_FALLBACK).  Negative n restores the default. */
 int qmpc_set_debug_overflow_slices(qmpc_handle h, int n);
+/* Test hook: the decoupled path's engine kernel may hold at most n rank-1 events per robot (0 = its compiled
+ * capacity); a robot that needs more is handed back to the one-kernel path (QMPC_ST_FALLBACK). */
+int qmpc_set_debug_engine_events(qmpc_handle h, int n);
 /* Test hook: on != 0 makes every slice of the 192-row class's global event pool look taken, so that every
  * workgroup of that class times out waiting for one: its robots must then be solved by the Schur-form engine
  * (QMPC_ST_FALLBACK set, same answer) instead of proceeding on a slice they do not own. */

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,11 +21,19 @@
   extern "C" size_t qmpc_c##RB##_smem(void);                                                    \
   extern "C" hipError_t qmpc_c##RB##_prepare(void);                                             \
   extern "C" int qmpc_c##RB##_resident(void);                                                   \
-  extern "C" hipError_t qmpc_c##RB##_launch(const QmpcParams* P, int grid, hipStream_t stream);
+  extern "C" hipError_t qmpc_c##RB##_launch(const QmpcParams* P, int grid, hipStream_t stream);   \
+  extern "C" int qmpc_c##RB##_resident_sweep(void);                                              \
+  extern "C" hipError_t qmpc_c##RB##_launch_sweep(const QmpcParams* P, int grid, hipStream_t stream);
 QMPC_DECLARE_CLASS(1)
 QMPC_DECLARE_CLASS(2)
 QMPC_DECLARE_CLASS(3)
 QMPC_DECLARE_CLASS(4)
+
+// the decoupled path's consumer (qmpc_engine.hip)
+extern "C" hipError_t qmpc_engine_prepare(void);
+extern "C" int qmpc_engine_resident(int rb);
+extern "C" int qmpc_engine_capacity(int rb);
+extern "C" hipError_t qmpc_engine_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
 
 extern "C" size_t qmpc_smem_bytes(int rb) {
   switch (rb) {
@@ -49,8 +58,13 @@ static hipError_t qmpc_prepare(void) {
   if ((e = qmpc_c1_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c4_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c2_prepare()) != hipSuccess) return e;
-  return qmpc_c3_prepare();
+  if ((e = qmpc_c3_prepare()) != hipSuccess) return e;
+  return qmpc_engine_prepare();
 }
+static hipError_t qmpc_launch_sweep(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
+  return rb == 2 ? qmpc_c2_launch_sweep(P, grid, stream) : (rb == 3 ? qmpc_c3_launch_sweep(P, grid, stream) : hipErrorInvalidValue);
+}
+static int qmpc_resident_sweep(int rb) { return rb == 2 ? qmpc_c2_resident_sweep() : (rb == 3 ? qmpc_c3_resident_sweep() : 0); }
 static hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
   switch (rb) {
     case 1: return qmpc_c1_launch(P, grid, stream);
@@ -87,7 +101,15 @@ struct qmpc_ctx {
   float leg_geom[4] = {0.062f, 0.209f, 0.195f, 0.004f};  // MiniCheetah.h:31-37 (abad, hip, knee, knee Y offset)
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
   int* d_lists = nullptr;      // [3][max_batch] robot ids handed to classes 4, 2 and 3
-  int* d_counts = nullptr;     // [2 sets][8]: list lengths of classes 4, 2, 3 (+pad), their queue heads, overflow-slice counter; ping-ponged between calls
+  int* d_counts = nullptr;     // [2 sets][QMPC_COUNTERS] (layout in qmpc_device.h); ping-ponged between calls
+  // decoupled path (sweep kernel -> work items -> engine kernel) of the 128- and 192-row classes: [0] class 2, [1] class 3
+  bool split = true;           // qmpc_set_split; QMPC_NO_SPLIT=1 in the environment switches it off at creation
+  double* d_wk_hinv[2] = {nullptr, nullptr};
+  double* d_wk_xu[2] = {nullptr, nullptr};
+  QmpcWorkHdr* d_wk_hdr[2] = {nullptr, nullptr};
+  int wk_cap[2] = {0, 0};
+  int* d_fb_lists = nullptr;   // [2][max_batch] robots the engine kernels hand back
+  int dbg_engine_events = 0;   // test hook: events the engine may hold per robot (0 = the compiled capacity)
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
@@ -161,6 +183,10 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 
 }  // namespace
 
+namespace {
+int ensure_split(qmpc_ctx* c, int rb);
+}
+
 extern "C" {
 
 int qmpc_abi_version(void) { return 13; }
@@ -182,8 +208,13 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   const size_t H = (size_t)max_horizon;
   hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
   if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 3 * (size_t)max_batch);
-  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 16);
-  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 16);
+  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 2 * QMPC_COUNTERS);
+  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 2 * QMPC_COUNTERS);
+  if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 2 * (size_t)max_batch);
+  {
+    const char* ns = std::getenv("QMPC_NO_SPLIT");
+    c->split = !(ns && ns[0] == '1');
+  }
   if (e == hipSuccess) {
     // a robot whose on-chip event pool fills up continues here; more than ov_nslice of them in one launch chain
     // fall back to the Schur-form engine
@@ -210,6 +241,12 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_evpool) hipFree(h->d_evpool);
     if (h->d_ovpool) hipFree(h->d_ovpool);
     if (h->d_evflags) hipFree(h->d_evflags);
+    if (h->d_fb_lists) hipFree(h->d_fb_lists);
+    for (int k = 0; k < 2; ++k) {
+      if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
+      if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
+      if (h->d_wk_hdr[k]) hipFree(h->d_wk_hdr[k]);
+    }
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->order_ev) hipEventDestroy(h->order_ev);
     if (h->host_ev) hipEventDestroy(h->host_ev);
@@ -357,6 +394,35 @@ int qmpc_set_debug_overflow_slices(qmpc_handle c, int n) {
   return QMPC_OK;
 }
 
+int qmpc_set_split(qmpc_handle c, int on) {
+  if (!c) return QMPC_ERR_ARG;
+  c->split = on != 0;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug_engine_events(qmpc_handle c, int n) {
+  if (!c || n < 0) return QMPC_ERR_ARG;
+  c->dbg_engine_events = n;
+  return QMPC_OK;
+}
+
+int qmpc_reserve(qmpc_handle c) {
+  if (!c) return QMPC_ERR_ARG;
+  if (!c->is_setup) return QMPC_ERR_STATE;
+  if (!c->split) return QMPC_OK;
+  DeviceGuard g(c->device);
+  // the classes the current horizon and stance hints can reach (same rule as the solve)
+  const int nmax = c->max_stance > 0 ? 3 * c->max_stance : 12 * c->horizon;
+  const int nreach = nmax < 12 * c->horizon ? nmax : 12 * c->horizon;
+  if (nreach > 96 && 3 * c->min_stance <= 128) {
+    if (const int rc = ensure_split(c, 2)) return rc;
+  }
+  if (nreach > 128) {
+    if (const int rc = ensure_split(c, 3)) return rc;
+  }
+  return QMPC_OK;
+}
+
 int qmpc_set_debug_pool_busy(qmpc_handle c, int on) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_pool_busy = on != 0;
@@ -386,6 +452,19 @@ bool command_ok(const qmpc_command* cmd) {
          cmd->p_foot && cmd->vel_des && cmd->yaw_des_true && cmd->rpy_comp && cmd->gait_offsets &&
          cmd->gait_durations && cmd->gait_iteration && cmd->world_position_desired && cmd->x_comp_integral &&
          !(cmd->gait_type && !cmd->stand_traj);  // a standing robot needs its stand_traj row
+}
+
+// work items of the decoupled path for size class rb (2 or 3): one per robot of the largest batch (the inverse is
+// 128 / 288 KiB per robot).  Allocated on the first call that can reach the class (qmpc_reserve does it up front)
+int ensure_split(qmpc_ctx* c, int rb) {
+  const int k = rb == 2 ? 0 : 1;
+  if (c->d_wk_hinv[k]) return QMPC_OK;
+  const size_t ld = rb == 2 ? 128 : 192, cap = (size_t)c->max_batch;
+  HIP_TRY(c, hipMalloc(&c->d_wk_hinv[k], sizeof(double) * cap * ld * ld));
+  HIP_TRY(c, hipMalloc(&c->d_wk_xu[k], sizeof(double) * cap * ld));
+  HIP_TRY(c, hipMalloc(&c->d_wk_hdr[k], sizeof(QmpcWorkHdr) * cap));
+  c->wk_cap[k] = (int)cap;
+  return QMPC_OK;
 }
 
 // one solve: inputs either as the record (`in`) or as the controller command (`cmd`, record built in stage 0)
@@ -491,8 +570,8 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.ev_spin = c->dbg_pool_busy ? 4 : (1 << 16);
   const unsigned set = c->call_no & 1u;
   c->call_no++;
-  int* cnt = c->d_counts + 8 * set;             // this call's counters (one per list)
-  int* cnt_next = c->d_counts + 8 * (set ^ 1u); // cleared by this call's first kernel
+  int* cnt = c->d_counts + QMPC_COUNTERS * set;             // this call's counters (one per list)
+  int* cnt_next = c->d_counts + QMPC_COUNTERS * (set ^ 1u); // cleared by this call's first kernel
   P.ov_count = cnt + 7;                         // slices of the overflow pool handed out in this call
   // ... and with a lower bound the classes that are too small for every robot are skipped
   int k0 = 0;
@@ -505,12 +584,59 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     const bool more = k + 1 < nclass_eff;
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;
-    if (chain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
-      HIP_TRY(c, hipMemsetAsync(c->d_evflags, c->dbg_pool_busy ? 1 : 0, sizeof(int) * (size_t)c->ev_nslot, stream));
     // the first class of the chain: one workgroup per robot; the later ones: one per resident slot, the list
     // is consumed as a queue (no workgroup is dispatched only to find its list entry missing)
+    const bool listed = k > k0;
+    // ---- decoupled path (128- and 192-row classes, exact solve, cold start): sweep kernel -> work items -> engine
+    // kernel -> (rarely) the monolithic kernel on the robots the engine handed back
+    const bool split = c->split && (chain[k] == 2 || chain[k] == 3) && !P.admm_mode && !P.ws;
+    if (split) {
+      const int sk = chain[k] == 2 ? 0 : 1;
+      if (const int rc = ensure_split(c, chain[k])) return rc;
+      QmpcParams A = P;
+      A.wk_hinv = c->d_wk_hinv[sk];
+      A.wk_xu = c->d_wk_xu[sk];
+      A.wk_hdr = c->d_wk_hdr[sk];
+      A.wk_count = cnt + 8 + sk;
+      A.wk_qhead = cnt + 10 + sk;
+      A.wk_ld = chain[k] == 2 ? 128 : 192;
+      A.wk_cap = c->wk_cap[sk];
+      A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
+      A.fb_list = c->d_fb_lists + (size_t)sk * c->max_batch;
+      A.fb_count = cnt + 12 + sk;
+      int grid = batch;
+      if (listed) {
+        const int res = qmpc_resident_sweep(chain[k]);
+        if (res > 0 && res < grid) grid = res;
+      }
+      HIP_TRY(c, qmpc_launch_sweep(chain[k], &A, grid, stream));
+      QmpcParams B = A;  // the engine: one robot per workgroup, the items as a queue
+      B.list = nullptr; B.count = nullptr; B.qhead = nullptr; B.clear_counts = nullptr;
+      B.next_list = nullptr; B.next_count = nullptr;
+      int gb = batch;
+      {
+        const int res = qmpc_engine_resident(chain[k]);
+        if (res > 0 && res < gb) gb = res;
+      }
+      HIP_TRY(c, qmpc_engine_launch(chain[k], &B, gb, stream));
+      QmpcParams F = P;  // robots handed back (event capacity exceeded): the monolithic kernel, list-consuming
+      F.list = A.fb_list; F.count = A.fb_count; F.qhead = cnt + 14 + sk; F.clear_counts = nullptr;
+      F.next_list = nullptr; F.next_count = nullptr;
+      F.status_or = QMPC_DEV_ST_FALLBACK;
+      if (chain[k] == 3 && c->d_evflags)
+        HIP_TRY(c, hipMemsetAsync(c->d_evflags, c->dbg_pool_busy ? 1 : 0, sizeof(int) * (size_t)c->ev_nslot, stream));
+      int gf = batch;
+      {
+        const int res = qmpc_resident_blocks(chain[k]);
+        if (res > 0 && res < gf) gf = res;
+      }
+      HIP_TRY(c, qmpc_launch(chain[k], &F, gf, stream));
+      continue;
+    }
+    if (chain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
+      HIP_TRY(c, hipMemsetAsync(c->d_evflags, c->dbg_pool_busy ? 1 : 0, sizeof(int) * (size_t)c->ev_nslot, stream));
     int grid = batch;
-    if (k > k0) {
+    if (listed) {
       const int res = qmpc_resident_blocks(chain[k]);
       if (res > 0 && res < grid) grid = res;
     }

@@ -23,6 +23,21 @@
 // ... and of the largest class's own pool: 160 events x (192 rows + 128 slots)
 #define QMPC_EV_SLICE3 (160 * 320)
 
+// per-call device counters, one set of QMPC_COUNTERS ints (two sets, ping-ponged between consecutive calls; the first
+// kernel of a chain zeroes the NEXT call's set):  [0..2] list lengths of classes 4, 2, 3   [4..6] their queue heads
+// [7] overflow-pool slices handed out   [8,9] work items produced by the sweep kernels of classes 2, 3   [10,11] the
+// engine kernels' queue heads   [12,13] robots handed back to the monolithic kernels   [14,15] their queue heads
+#define QMPC_COUNTERS 16
+
+// decoupled path: a sweep workgroup (or the long-horizon producer) leaves its robot's explicit inverse,
+// unconstrained minimiser and stance list in a work item; single-robot engine workgroups consume the items
+#define QMPC_WK_SLOTS_MAX 192  // stance slots an item can describe (three 64-lane groups; trot at horizon 36 has 72)
+struct QmpcWorkHdr {
+  int rid, n, nst, status0;              // robot, reduced size 3 nst, stance foot-steps, status bits so far
+  float fmaxk[QMPC_WK_SLOTS_MAX];        // f_max * gait of stance slot s (float product like SolverMPC.cpp:361)
+  unsigned char sidx[QMPC_WK_SLOTS_MAX]; // foot-step 4 step + foot of stance slot s
+};
+
 // leading dimension of the debug dump (largest padded size, 3 * 64)
 #define QMPC_DBG_LD 192
 
@@ -76,6 +91,20 @@ struct QmpcParams {
   double* ovpool;
   int* ov_count;
   int ov_nslice;
+  // decoupled path: work items [wk_cap] of this size class -- H^-1 (wk_ld x wk_ld doubles, row-major, symmetric),
+  // x_u (wk_ld doubles), header; *wk_count = items produced so far (sweep workgroups take the next index),
+  // *wk_qhead = queue head of the engine workgroups; fb_list / fb_count: robots the engine hands back to the
+  // monolithic kernel of the class (event capacity exceeded, lost definiteness)
+  double* wk_hinv;
+  double* wk_xu;
+  QmpcWorkHdr* wk_hdr;
+  int* wk_count;
+  int* wk_qhead;
+  int wk_ld, wk_cap;
+  int wk_kev;  // events the engine may hold per robot (test hook; the compiled capacity when larger)
+  int* fb_list;
+  int* fb_count;
+  int status_or;  // bits OR-ed into the status of every robot this launch solves (the hand-back launch: QMPC_ST_FALLBACK)
   // warm start (nullptr = cold): [batch][QMPC_WS_STRIDE] working set of the previous cycle as global
   // constraint ids 5 * (4 step + foot) + type, -1 = empty; read slid by ws_shift horizon steps, rewritten
   // with this cycle's final working set

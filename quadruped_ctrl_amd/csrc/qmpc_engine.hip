@@ -1,0 +1,719 @@
+// qmpc_engine.hip -- the CONSUMER half of the decoupled path: the dual active set (Goldfarb-Idnani, event form)
+// on an explicit inverse that lives in global memory, for the size classes whose robots iterate long
+// (128- and 192-row classes; the long-horizon producer uses the same engine).
+//
+// What it replaces in the reference: the qpOASES call of solve_mpc (src/MPC_Ctrl/SolverMPC.cpp:527-557: cold
+// QProblem::init on H_red, g_red, A_red, then q_soln scatter) -- same unique minimiser (H is positive definite).
+//
+// Why a second engine.  In the monolithic kernel (qmpc_kernels.hip) a robot of the large classes holds
+// a whole CU -- the packed inverse fills its LDS -- while ONE of its 8 / 12 waves iterates (73 % of the wave-cycles
+// parked, PMC).  Here the producer (qmpc_sweep_kernel, or the Riccati producer for long horizons) writes H^-1 to an
+// L2 / Infinity-Cache resident work item and leaves; this kernel runs one robot per small workgroup, several per CU:
+//   * wave 0 is the ENGINE: x, multipliers, working set in registers (lane = variable / stance slot / working slot),
+//     the two columns of H^-1 an iteration needs are two or three coalesced row loads (the matrix is symmetric);
+//   * waves 1..NH are event HOLDERS: the rank-1 events (z~, g~) that represent the projected inverse
+//         P = H^-1 - sum_add z~ z~^T + sum_drop z~ z~^T,   N* = sum z~ g~^T,   S^-1 = sum_add g~ g~^T - sum_drop g~ g~^T
+//     never leave the REGISTER FILE: event e lives in holder 1 + e mod NH, registers [e / NH] (RE + KQ doubles per
+//     lane and event, statically indexed).  An iteration's accumulation z -= +-y z~, r += y g~ (y = z~^T c_p) runs in
+//     all holders at once on their own events, operands by readlane -- no event pool in LDS or global memory, no
+//     loads at all in the loop that bounds the monolithic engine (~22 cycles per load instruction whoever issues it).
+//     Two workgroup barriers per iteration carry the request and the partial sums (fixed split, fixed order of the
+//     final sum: results do not depend on timing).
+// A robot that needs more events than the holders' registers take (NH * MAXL), or whose projected inverse loses
+// definiteness numerically, is handed back to the monolithic kernel of its class through a list (QMPC_ST_FALLBACK).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "qmpc_device.h"
+#include "qmpc_cmd.h"
+#include "qmpc_wave.h"
+
+namespace {
+
+// RE: 64-row blocks of a variable-indexed vector (LD = 64 RE padded rows); KQ: working-set slots per lane (64 KQ
+// slots); SQ: stance slots per lane (64 SQ foot-steps in stance at most); NW: waves per workgroup (1 engine + NH
+// holders); MAXL: events per holder.
+// MAXE: events the ENGINE wave itself holds, in LDS (it is idle while the holders accumulate: it takes a share of the
+// events like they do, and everything beyond the holders' registers).
+template <int RE_, int KQ_, int SQ_, int NW_, int MAXL_, int MAXE_>
+struct ECfg {
+  static constexpr int RE = RE_, KQ = KQ_, SQ = SQ_, NW = NW_, MAXL = MAXL_, MAXE = MAXE_;
+  static constexpr int NH = NW - 1, NP = 64 * RE, KS = 64 * KQ, NSL = 64 * SQ, NT = 64 * NW;
+  static constexpr int NRR = (NH + 1) * MAXL;     // events dealt round-robin over engine + holders
+  static constexpr int KEV = NH * MAXL + MAXE;    // capacity
+  static constexpr int EV = NP + KS;
+  static_assert(MAXE >= MAXL && MAXE <= 64, "engine-held events");
+  static_assert(NSL <= QMPC_WK_SLOTS_MAX, "stance slots of a work item");
+  static_assert(5 * NSL <= 1024, "constraint id in ten bits of the selection key");
+};
+
+enum { CMD_DONE = 0, CMD_ACC = 1, CMD_DROPACC = 2 };
+
+// profiling hook (qmpc_set_debug_clock): shader-clock stamps of ONE iteration of the engine wave (slots 0..7) and of
+// holder 1 (slots 8..11); tools/engine_phase.py
+#ifndef QMPC_EDBG_ITER
+#define QMPC_EDBG_ITER 20
+#endif
+#define QMPC_ESTAMP(k)                                                                   \
+  do {                                                                                   \
+    if (dbg_clk && lane == 0 && iters == QMPC_EDBG_ITER) dbg_clk[(k)] = clock64();      \
+  } while (0)
+
+template <class C>
+struct ESmem {
+  QmpcParams par;
+  int rid, n, nst, status0, qnext;
+  float fmaxk[C::NSL];
+  unsigned char sidx[C::NSL];
+  // the engine's request to the holders, and the event it staged for one of them in the previous round
+  // (three 16-byte words: written with three stores, read by every holder with three broadcast loads in flight together)
+  struct alignas(16) Req {
+    int cmd, pj1, pj2, l;
+    double pa1, pa2;
+    int ing_valid, ing_owner, ing_li, ing_flags;  // ing_flags: bit 0 = drop event, bits 8.. = 1 + slot to clear
+  } rq;
+  alignas(16) double stage[C::EV];       // the new event (z~[NP], g~[KS])
+  alignas(16) double epool[C::MAXE][C::EV];  // the engine wave's own events
+  double part[C::NH][C::EV];             // the holders' partial sums (z[NP], r[KS])
+  double xl[C::NP];                      // x, variable-indexed, for the stance-slot lanes of the selection
+  double D[C::NP];                       // diag(H^-1)
+  float fb[12];
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
+// spaces, i.e. it waits for the wave's outstanding GLOBAL loads too (one counter for loads and stores on gfx9) -- the
+// engine wave's H^-1 column loads would be waited for at (A) with every other wave behind them.  The data the waves of
+// this kernel exchange lives in LDS; global memory is only read (work item) or written at the very end (results).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// f(integral_constant<LI>) for LI = 0 .. count-1 (count <= N, wave-uniform) as NESTED ifs: straight-line code with one
+// not-taken branch per event and a single exit -- a flat chain of `if (LI < count)` was laid out by the compiler as
+// blocks scattered over the kernel, a taken branch (instruction refetch) per event
+template <int LI, int N>
+struct Upto {
+  template <class F>
+  static __device__ __forceinline__ void run(int count, F&& f) {
+    if (LI < count) {
+      f(std::integral_constant<int, LI>{});
+      Upto<LI + 1, N>::run(count, f);
+    }
+  }
+};
+template <int N>
+struct Upto<N, N> {
+  template <class F>
+  static __device__ __forceinline__ void run(int, F&&) {}
+};
+
+// f(q1c, q2c) with the 64-row blocks of the two variables of a constraint row as compile-time constants: j2 - j1 <= 2
+// (same stance slot), so q2 is q1 or q1 + 1
+template <int RE, class F>
+__device__ __forceinline__ void dispatch_blocks(int q1, int q2, F&& f) {
+  StaticFor<0, RE>::run([&](auto qa) __attribute__((always_inline)) {
+    constexpr int QA = decltype(qa)::value;
+    if (q1 == QA) {
+      if (q2 == QA) f(std::integral_constant<int, QA>{}, std::integral_constant<int, QA>{});
+      else if constexpr (QA + 1 < RE) f(std::integral_constant<int, QA>{}, std::integral_constant<int, QA + 1>{});
+    }
+  });
+}
+
+template <class C, bool WARM>
+__device__ __forceinline__ void engine_item(const int item, const int tid, ESmem<C>& S, const QmpcParams& PK) {
+  constexpr int RE = C::RE, KQ = C::KQ, SQ = C::SQ, NH = C::NH, NP = C::NP, KS = C::KS, MAXL = C::MAXL, LD = C::NP;
+  constexpr int MAXE = C::MAXE, EV = C::EV;
+  using Req = typename ESmem<C>::Req;
+  const QmpcParams& P = S.par;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GlobalF64* const Hi = (const GlobalF64*)PK.wk_hinv + (size_t)item * (LD * LD);
+  const GlobalF64* const xu = (const GlobalF64*)PK.wk_xu + (size_t)item * LD;
+  const QmpcWorkHdr* const hd = PK.wk_hdr + item;
+  // ---- the item's header and the diagonal of H^-1 -> LDS; the parameter block is parked once per workgroup (kernel)
+  if (tid == 0) {
+    S.rid = hd->rid;
+    S.n = hd->n;
+    S.nst = hd->nst;
+    S.status0 = hd->status0;
+    S.rq.ing_valid = 0;
+    S.rq.cmd = CMD_DONE;
+  }
+  for (int k = tid; k < C::NSL; k += C::NT) {
+    S.fmaxk[k] = hd->fmaxk[k < QMPC_WK_SLOTS_MAX ? k : 0];
+    S.sidx[k] = hd->sidx[k < QMPC_WK_SLOTS_MAX ? k : 0];
+  }
+  for (int k = tid; k < NP; k += C::NT) {
+    S.D[k] = Hi[(size_t)k * LD + k];
+    S.xl[k] = xu[k];
+  }
+  __syncthreads();
+  const int n = S.n, nst = S.nst, rid = S.rid;
+  const int h = P.horizon;
+  long long* dbg_clk = P.dbg_clk ? P.dbg_clk + (size_t)rid * 16 : nullptr;
+  // event e: dealt round-robin over the engine wave (owner 0, LDS) and the holders (owners 1..NH, registers) while the
+  // holders have room, then to the engine wave's LDS pool
+  auto ev_owner = [](int e) __attribute__((always_inline)) { return e < C::NRR ? e % (NH + 1) : 0; };
+  auto ev_index = [](int e) __attribute__((always_inline)) { return e < C::NRR ? e / (NH + 1) : MAXL + (e - C::NRR); };
+
+  if (wv == 0) {
+    // =============================================================== the engine wave
+    const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
+    const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
+    const int kev = __builtin_amdgcn_readfirstlane(P.wk_kev < C::KEV ? P.wk_kev : C::KEV);
+    auto uni = [](bool cnd) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(cnd) != 0ull; };
+    double xv[RE];
+#pragma unroll
+    for (int q = 0; q < RE; ++q) xv[q] = (lane + 64 * q < n) ? S.xl[lane + 64 * q] : 0.0;
+    double fmx[SQ];
+    unsigned amask[SQ];
+#pragma unroll
+    for (int s = 0; s < SQ; ++s) {
+      fmx[s] = (lane + 64 * s < nst) ? (double)S.fmaxk[lane + 64 * s] : 0.0;
+      amask[s] = 0u;
+    }
+    int wcid[KQ];
+    double lam[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      wcid[k] = -1;
+      lam[k] = 0.0;
+    }
+    int khw = 0, status = 0, nev = 0, iters = 0;
+    int nle = 0;                        // events in the engine wave's own LDS pool
+    unsigned long long dropme = 0ull;   // ... that are drop events
+    bool retry = false;
+    int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
+    double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
+    auto rsqrt_full = [&](double d) __attribute__((always_inline)) {
+      double y = __builtin_amdgcn_rsq(d);
+      double e = __builtin_fma(-d * y, y, 1.0);
+      y = __builtin_fma(0.5 * y, e, y);
+      e = __builtin_fma(-d * y, y, 1.0);
+      y = __builtin_fma(0.5 * y, e, y);
+      return y;
+    };
+    // the engine wave's share of an accumulation, over its own events in LDS, four per trip:
+    //   ACC:     y = z~^T c_p          zs += -+y z~ (add / drop event)   rs += y g~
+    //   DROPACC: y = g~[l]             zs += y z~                        rs += +-y g~
+    auto own_events = [&](auto accc, int l, double (&zs)[RE], double (&rs)[KQ]) __attribute__((always_inline)) {
+      constexpr bool ACC = decltype(accc)::value;
+#pragma unroll 1
+      for (int t0 = 0; t0 < nle; t0 += 4) {
+        double ya[4], yb[4], zl[4][RE], gl[4][KQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* ev = S.epool[(t0 + u < nle) ? t0 + u : 0];
+          ya[u] = ACC ? ev[pj1] : ev[NP + l];
+          yb[u] = ACC ? ev[pj2] : 0.0;
+#pragma unroll
+          for (int q = 0; q < RE; ++q) zl[u][q] = ev[lane + 64 * q];
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) gl[u][k] = ev[NP + lane + 64 * k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool isdrop = ((dropme >> (t0 + u)) & 1ull) != 0ull;
+          double y = ACC ? __builtin_fma(pa2, yb[u], pa1 * ya[u]) : ya[u];
+          if (!(t0 + u < nle)) y = 0.0;
+          const double yz = ACC ? (isdrop ? y : -y) : y;
+          const double yr = ACC ? y : (isdrop ? -y : y);
+#pragma unroll
+          for (int q = 0; q < RE; ++q) zs[q] = __builtin_fma(yz, zl[u][q], zs[q]);
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gl[u][k], rs[k]);
+        }
+      }
+    };
+    // one round with the holders: the request goes up, (A), everybody accumulates over the events it holds, (B), the
+    // partial sums come back and are added in a fixed order.  `pre` runs between the barriers
+    auto round = [&](int cmd, int l, double (&zs)[RE], double (&rs)[KQ], auto&& pre) __attribute__((always_inline)) {
+      if (lane == 0) {
+        *reinterpret_cast<int4*>(&S.rq.cmd) = int4{cmd, pj1, pj2, l};
+        st2(&S.rq.pa1, pa1, pa2);
+      }
+      lds_barrier();  // (A)
+      pre();
+      lds_barrier();  // (B)
+      if (lane == 0) S.rq.ing_valid = 0;  // (the staged event, if any, has been taken)
+#pragma unroll
+      for (int w = 0; w < NH; ++w) {
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zs[q] += S.part[w][lane + 64 * q];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) rs[k] += S.part[w][NP + lane + 64 * k];
+      }
+    };
+    // the new event goes to its owner: straight into the engine wave's LDS pool, or staged for a holder (which takes it
+    // into its registers at the next (A)); clear_slot >= 0: that working-set slot was dropped -- its column of every
+    // g~ is cleared (the holders do theirs when they see the flag)
+    auto place_event = [&](const double (&zv)[RE], const double (&gv)[KQ], bool is_drop, int clear_slot) __attribute__((always_inline)) {
+      const int owner = ev_owner(nev), li = ev_index(nev);
+      double* const dst = (owner == 0) ? S.epool[li] : S.stage;
+#pragma unroll
+      for (int q = 0; q < RE; ++q) dst[lane + 64 * q] = zv[q];
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) dst[NP + lane + 64 * k] = gv[k];
+      if (clear_slot >= 0 && lane < nle) S.epool[lane][NP + clear_slot] = 0.0;
+      if (owner == 0) {
+        if (is_drop) dropme |= (1ull << li);
+        nle = li + 1;
+      }
+      if (lane == 0 && (owner != 0 || clear_slot >= 0))
+        *reinterpret_cast<int4*>(&S.rq.ing_valid) = int4{1, owner, li, (is_drop ? 1 : 0) | ((clear_slot + 1) << 8)};
+      nev += 1;
+    };
+    __builtin_amdgcn_s_setprio(2);  // the serial part of the workgroup
+    double c1[RE], c2[RE];  // the two columns of H^-1 of the constraint being added (rows of the symmetric work item)
+    // ---- the most violated constraint outside the working set (normalised by its row norm) becomes p, and the loads of
+    // its two columns are issued; false: none is violated (optimal) or the iteration limit is reached.  The stance-slot
+    // lanes read x from its variable-indexed copy in LDS (kept current by every step), not through cross-lane gathers
+    auto select_next = [&]() __attribute__((always_inline)) {
+      unsigned key = 0;
+#pragma unroll
+      for (int s = 0; s < SQ; ++s) {
+        const int sl = lane + 64 * s;
+        const int sc = sl < nst ? sl : 0;
+        const double x0 = S.xl[3 * sc], x1 = S.xl[3 * sc + 1], x2 = S.xl[3 * sc + 2];
+        if (sl < nst) {
+          const double fx = mi * x0, fy = mi * x1;
+          double vmin = 0.0;
+          int tmin = -1;
+          const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx[s] - x2};
+#pragma unroll
+          for (int ty = 0; ty < 5; ++ty) {
+            const bool cand = !((amask[s] >> ty) & 1u) && sv[ty] < vmin;
+            vmin = cand ? sv[ty] : vmin;
+            tmin = cand ? ty : tmin;
+          }
+          if (vmin < -tol) {
+            const unsigned kk = (__float_as_uint((float)(-vmin)) & ~0x3FFu) | (unsigned)(5 * sl + tmin);
+            key = kk > key ? kk : key;
+          }
+        }
+      }
+      const unsigned best = wave_max_u32(key);
+      if (best == 0u) return false;
+      if (iters >= max_iter) {
+        status |= QMPC_DEV_ST_MAXITER;
+        return false;
+      }
+      p_e = (int)(best & 0x3FFu);
+      psl = p_e / 5;
+      pty = p_e - 5 * psl;
+      con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
+      p_rhs = (pty == 4) ? -(double)S.fmaxk[psl] : 0.0;
+      lp = 0.0;
+      // in flight across barrier (A) (which only orders LDS) and the accumulation over the events, and -- from the second
+      // iteration on -- across the placement of the previous event; consumed right before (B)
+#pragma unroll
+      for (int q = 0; q < RE; ++q) {
+        c1[q] = Hi[(size_t)pj1 * LD + lane + 64 * q];
+        c2[q] = Hi[(size_t)pj2 * LD + lane + 64 * q];
+      }
+      return true;
+    };
+    bool have_p = select_next();
+    while (have_p) {
+      iters = __builtin_amdgcn_readfirstlane(iters);
+      khw = __builtin_amdgcn_readfirstlane(khw);
+      nev = __builtin_amdgcn_readfirstlane(nev);
+      nle = __builtin_amdgcn_readfirstlane(nle);
+      status = __builtin_amdgcn_readfirstlane(status);
+      p_e = __builtin_amdgcn_readfirstlane(p_e);
+      psl = __builtin_amdgcn_readfirstlane(psl);
+      pty = __builtin_amdgcn_readfirstlane(pty);
+      pj1 = __builtin_amdgcn_readfirstlane(pj1);
+      pj2 = __builtin_amdgcn_readfirstlane(pj2);
+      QMPC_ESTAMP(0);
+      // ---- room for one more event?  Every pass leaves exactly one (add or drop)
+      if (nev >= kev) {
+        retry = true;
+        break;
+      }
+      // ---- z = P c_p (variable lanes), r = N*^T c_p (working-slot lanes)
+      QMPC_ESTAMP(1);
+      double z[RE], rw[KQ];
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) rw[k] = 0.0;
+#pragma unroll
+      for (int q = 0; q < RE; ++q) z[q] = 0.0;
+      round(CMD_ACC, 0, z, rw, [&]() __attribute__((always_inline)) {
+        QMPC_ESTAMP(2);
+        own_events(std::true_type{}, 0, z, rw);
+#pragma unroll
+        for (int q = 0; q < RE; ++q)
+          if (lane + 64 * q < n) z[q] += __builtin_fma(pa2, c2[q], pa1 * c1[q]);
+        if (dbg_clk && lane == 0 && iters == QMPC_EDBG_ITER) {
+          double zs = 0.0;  // (the stamp waits for the loads)
+#pragma unroll
+          for (int q = 0; q < RE; ++q) zs += z[q];
+          asm volatile("" ::"v"(zs));
+          dbg_clk[3] = clock64();
+        }
+      });
+      QMPC_ESTAMP(4);
+      const double delta = __builtin_fma(pa2, lane_elem<RE>(z, pj2), pa1 * lane_elem<RE>(z, pj1));
+      const double cn = __builtin_fma(pa2 * pa2, S.D[pj2], pa1 * pa1 * S.D[pj1]);  // scale of c_p^T H^-1 c_p
+      const double sp = __builtin_fma(pa2, S.xl[pj2], pa1 * S.xl[pj1]) - p_rhs;
+      const bool dep = uni(!(delta > 1e-11 * cn));
+      const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
+      double ratio[KQ], rmin = __builtin_inf();
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        ratio[k] = __builtin_inf();
+        if (wcid[k] >= 0 && rw[k] > 0.0) {
+          const double qv = lam[k] * fast_rcp(rw[k]);
+          ratio[k] = qv > 0.0 ? qv : 0.0;
+        }
+        rmin = (k == 0 || ratio[k] < rmin) ? ratio[k] : rmin;
+      }
+      double t1 = __builtin_inf();
+      int l = -1;
+      if (khw > 0 && uni(rmin < __builtin_inf())) {
+        t1 = wave_min_pos_f64(rmin);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+          const unsigned long long hit = __ballot(ratio[k] == t1);
+          if (l < 0 && hit != 0ull) l = 64 * k + __ffsll((long long)hit) - 1;
+        }
+      }
+      const double t = (t2 <= t1) ? t2 : t1;
+      if (dbg_clk && lane == 0 && iters == QMPC_EDBG_ITER) {
+        asm volatile("" ::"v"(t));
+        dbg_clk[5] = clock64();
+      }
+      if (uni(!(t < __builtin_inf()))) {
+        status |= QMPC_DEV_ST_INFEASIBLE;
+        break;
+      }
+      if (!dep) {
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          xv[q] = __builtin_fma(t, z[q], xv[q]);
+          S.xl[lane + 64 * q] = xv[q];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) lam[k] -= t * rw[k];
+      lp += t;
+      iters += 1;
+      if (uni(t2 <= t1)) {
+        // ---- full step: p joins the working set in the first free slot (an add event)
+        int qslot = -1;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+          const unsigned long long fm = __ballot(wcid[k] < 0);
+          if (qslot < 0 && fm != 0ull) qslot = 64 * k + __ffsll((long long)fm) - 1;
+        }
+        if (qslot < 0) {
+          retry = true;  // out of working-set slots
+          break;
+        }
+        // the event's entries need the working set as it was: g~_w = -r_w / sqrt(delta) on the slots in use, 1 / sqrt(delta)
+        // on the new one
+        const double s = rsqrt_full(delta);
+        double zv[RE], gv[KQ];
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zv[q] = z[q] * s;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == qslot) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+          if (lane + 64 * k == qslot) {
+            wcid[k] = p_e;
+            lam[k] = lp;
+          }
+#pragma unroll
+        for (int s2 = 0; s2 < SQ; ++s2)
+          if (lane + 64 * s2 == psl) amask[s2] |= (1u << pty);
+        khw = (qslot + 1 > khw) ? qslot + 1 : khw;
+        // the NEXT constraint is chosen, and the loads of its columns issued, BEFORE the event of this one is placed:
+        // the L2 / Infinity-Cache latency of those loads (the inverse was written by another kernel, every column is a
+        // first touch) overlaps the placement, the request and the holders' accumulation
+        have_p = select_next();
+        place_event(zv, gv, false, -1);
+      } else {
+        // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event).  u = N*_l (variable
+        // lanes), sc = S^-1[:, l] (slot lanes) over ALL events: a second round.  p stays (its columns are still in c1, c2)
+        double u[RE], sc[KQ];
+#pragma unroll
+        for (int q = 0; q < RE; ++q) u[q] = 0.0;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) sc[k] = 0.0;
+        round(CMD_DROPACC, l, u, sc, [&]() __attribute__((always_inline)) { own_events(std::false_type{}, l, u, sc); });
+        const double gamma = lane_elem<KQ>(sc, l);
+        if (uni(!(gamma > 0.0))) {
+          retry = true;  // numerically lost S^-1[l][l] > 0
+          break;
+        }
+        const double sg = rsqrt_full(gamma);
+        const int de = lane_elem<KQ>(wcid, l);
+        double zv[RE], gv[KQ];
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zv[q] = u[q] * sg;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
+        place_event(zv, gv, true, l);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+          if (lane + 64 * k == l) {
+            wcid[k] = -1;
+            lam[k] = 0.0;
+          }
+        const int dsl = de / 5, dty = de - 5 * dsl;
+#pragma unroll
+        for (int s2 = 0; s2 < SQ; ++s2)
+          if (lane + 64 * s2 == dsl) amask[s2] &= ~(1u << dty);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (dbg_clk && lane == 0 && iters == QMPC_EDBG_ITER + 1) dbg_clk[7] = clock64();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (lane == 0) S.rq.cmd = CMD_DONE;
+    lds_barrier();  // (A) of the last round: the holders leave
+    if (dbg_clk && lane == 0) dbg_clk[6] = clock64();
+    if (!retry) {
+      // outputs: get_solution(0..11) = forces of the four feet at horizon step 0 (convexMPC_interface.cpp:175-180,
+      // ConvexMPCLocomotion.cpp:672-685); an iterate the method abandoned is not a solution: zeros and a status
+      const bool dead = (status & (QMPC_DEV_ST_INFEASIBLE | QMPC_DEV_ST_WS_FULL)) != 0;
+      if (lane < 12) P.grf[(size_t)rid * 12 + lane] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+      bool nf = false;
+#pragma unroll
+      for (int q = 0; q < RE; ++q) {
+        const int j = lane + 64 * q;
+        if (j < n && !dead) {
+          const int k = S.sidx[j / 3], ax = j % 3;  // foot-step of this variable
+          if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax] = (float)xv[q];
+          if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax] = xv[q];
+        }
+        nf |= (j < n) && !(__builtin_fabs(xv[q]) < __builtin_inf());
+      }
+      if (__ballot(nf)) status |= QMPC_DEV_ST_NONFINITE;
+      const bool cmdm = P.c_position != nullptr;
+      if (lane == 0) {
+        P.status[rid] = S.status0 | status;
+        if (P.iters) P.iters[rid] = iters;
+        if (cmdm) {
+          // the controller state owned by the packer, advanced by the run that produces the result
+          // (ConvexMPCLocomotion.cpp:534-545, :632-640)
+          const float* pos = P.c_position + (size_t)rid * 3;
+          if (!(P.c_gait_type && P.c_gait_type[rid] == 4)) {
+            P.c_wpd[(size_t)rid * 2 + 0] = qmpc_cmd_clamp(P.c_wpd[(size_t)rid * 2 + 0], pos[0]);
+            P.c_wpd[(size_t)rid * 2 + 1] = qmpc_cmd_clamp(P.c_wpd[(size_t)rid * 2 + 1], pos[1]);
+          }
+          P.c_xci[rid] = qmpc_cmd_xci_next(P.c_xci[rid], pos[2], P.c_body_height, (float)P.dt, P.c_v_world[(size_t)rid * 3 + 0]);
+        }
+      }
+      if (cmdm && P.f_ff) {
+        if (lane < 12) S.fb[lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          const int j = lane + 64 * q;
+          if (j < n && !dead && S.sidx[j / 3] < 4) S.fb[3 * S.sidx[j / 3] + j % 3] = (float)xv[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 12) {
+          const int leg = lane / 3, ii = lane - 3 * leg;
+          P.f_ff[(size_t)rid * 12 + lane] =
+              qmpc_cmd_f2b(P.c_r_body + (size_t)rid * 9 + 3 * ii, S.fb[3 * leg], S.fb[3 * leg + 1], S.fb[3 * leg + 2]);
+        }
+      }
+    } else if (lane == 0) {
+      // handed back: the monolithic kernel of the class solves this robot from scratch (its pool is larger)
+      const int slot = atomicAdd(P.fb_count, 1);
+      P.fb_list[slot] = rid;
+    }
+  } else {
+    // =============================================================== an event holder
+    double zt[MAXL][RE], gt[MAXL][KQ];
+#pragma unroll
+    for (int li = 0; li < MAXL; ++li) {
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zt[li][q] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) gt[li][k] = 0.0;
+    }
+    int nloc = 0, hround = 0;
+    unsigned long long dropm = 0ull;  // local events that are drop events
+    while (true) {
+      lds_barrier();  // (A)
+      const bool hst = dbg_clk && wv == 1 && lane == 0 && hround == QMPC_EDBG_ITER;  // (rounds ~ iterations while nothing is dropped)
+      hround += 1;
+      if (hst) dbg_clk[8] = clock64();
+      // the whole request with three broadcast loads in flight together (one LDS round trip, not one per field)
+      int4 r0 = *reinterpret_cast<const int4*>(&S.rq.cmd);
+      F64x2 r1 = ld2(&S.rq.pa1);
+      int4 r2 = *reinterpret_cast<const int4*>(&S.rq.ing_valid);
+      // ... and the staged event with them, whoever it is for (no second round trip for its owner)
+      double zin[RE], gin[KQ];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zin[q] = S.stage[lane + 64 * q];
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) gin[k] = S.stage[NP + lane + 64 * k];
+      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z),
+                   "+v"(r2.w), "+v"(zin[0]), "+v"(gin[0]));
+      const int cmd = __builtin_amdgcn_readfirstlane(r0.x);
+      if (cmd == CMD_DONE) break;
+      nloc = __builtin_amdgcn_readfirstlane(nloc);
+      // ---- the event the engine staged in the previous round (if any): a dropped working-set slot's column of every
+      // g~ is cleared; the owner takes the record into its registers
+      if (__builtin_amdgcn_readfirstlane(r2.x) != 0) {
+        const int flags = __builtin_amdgcn_readfirstlane(r2.w);
+        const int clr = (flags >> 8) - 1;
+        if (clr >= 0) {
+          const int ck = clr >> 6, cl = clr & 63;
+          Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
+            constexpr int li = decltype(lic)::value;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) gt[li][k] = (k == ck && lane == cl) ? 0.0 : gt[li][k];
+          });
+        }
+        if (__builtin_amdgcn_readfirstlane(r2.y) == wv) {
+          const int myli = __builtin_amdgcn_readfirstlane(r2.z);
+          StaticFor<0, MAXL>::run([&](auto lic) __attribute__((always_inline)) {
+            constexpr int li = decltype(lic)::value;
+            if (li == myli) {
+#pragma unroll
+              for (int q = 0; q < RE; ++q) zt[li][q] = zin[q];
+#pragma unroll
+              for (int k = 0; k < KQ; ++k) gt[li][k] = gin[k];
+              // (a different instruction at the END of every case: the compiler otherwise sinks the stores of all cases
+              //  into one store through a pointer chosen at run time, and the whole register array becomes scratch)
+              asm volatile("; event registers %0" ::"n"(li));
+            }
+          });
+          if (flags & 1) dropm |= (1ull << myli);
+          nloc = myli + 1;
+        }
+      }
+      if (hst) dbg_clk[9] = clock64();
+      double zp[RE], rp[KQ];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zp[q] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) rp[k] = 0.0;
+      if (cmd == CMD_ACC) {
+        // z -= +-y z~ , r += y g~ with y = z~^T c_p = a1 z~[j1] + a2 z~[j2] over this holder's events; the two entries of
+        // z~ come by readlane from registers whose 64-row block is a compile-time constant of the specialised loop
+        const int hj1 = __builtin_amdgcn_readfirstlane(r0.y), hj2 = __builtin_amdgcn_readfirstlane(r0.z);
+        const double ha1 = readlane_f64(r1.x, 0), ha2 = readlane_f64(r1.y, 0);
+        const int l1 = hj1 & 63, l2 = hj2 & 63;
+        dispatch_blocks<RE>(hj1 >> 6, hj2 >> 6, [&](auto q1c, auto q2c) __attribute__((always_inline)) {
+          constexpr int Q1 = decltype(q1c)::value, Q2 = decltype(q2c)::value;
+          Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
+            constexpr int li = decltype(lic)::value;
+            const double y = __builtin_fma(ha2, readlane_f64(zt[li][Q2], l2), ha1 * readlane_f64(zt[li][Q1], l1));
+            const double ys = ((dropm >> li) & 1ull) ? y : -y;
+#pragma unroll
+            for (int q = 0; q < RE; ++q) zp[q] = __builtin_fma(ys, zt[li][q], zp[q]);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) rp[k] = __builtin_fma(y, gt[li][k], rp[k]);
+          });
+        });
+      } else {
+        // u = N*_l = sum z~ g~[l] ,  sc = S^-1[:, l] = sum_add g~ g~[l] - sum_drop g~ g~[l]
+        const int hl = __builtin_amdgcn_readfirstlane(r0.w);
+        Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
+          constexpr int li = decltype(lic)::value;
+          const double y = lane_elem<KQ>(gt[li], hl);
+          const double ys = ((dropm >> li) & 1ull) ? -y : y;
+#pragma unroll
+          for (int q = 0; q < RE; ++q) zp[q] = __builtin_fma(y, zt[li][q], zp[q]);
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) rp[k] = __builtin_fma(ys, gt[li][k], rp[k]);
+        });
+      }
+      if (hst) {
+        double zs = 0.0;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zs += zp[q];
+        asm volatile("" ::"v"(zs));
+        dbg_clk[10] = clock64();
+      }
+      double* const mine = S.part[wv - 1];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) mine[lane + 64 * q] = zp[q];
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) mine[NP + lane + 64 * k] = rp[k];
+      if (hst) dbg_clk[11] = clock64();
+      lds_barrier();  // (B)
+    }
+  }
+  __syncthreads();  // every wave is done with this item's LDS state
+}
+
+}  // namespace
+
+// One robot per workgroup, the items of the class consumed as a queue (entry blockIdx.x first, then whatever the head
+// counter hands out).  WARM is reserved (the warm start across MPC cycles runs in the monolithic kernels).
+template <int RE, int KQ, int SQ, int NW, int MAXL, int MAXE>
+__global__ __launch_bounds__(64 * NW, 2) void qmpc_engine_kernel(const QmpcParams P) {
+  using C = ECfg<RE, KQ, SQ, NW, MAXL, MAXE>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_esmem[];
+  ESmem<C>& S = *reinterpret_cast<ESmem<C>*>(qmpc_esmem);
+  const int nitems = *P.wk_count;
+  if ((int)blockIdx.x >= nitems) return;  // uniform
+  static_assert(sizeof(QmpcParams) % 4 == 0 && sizeof(QmpcParams) / 4 <= 64 * NW, "parameter block copy");
+  if (threadIdx.x < sizeof(QmpcParams) / 4)
+    reinterpret_cast<uint32_t*>(&S.par)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P)[threadIdx.x];
+  __syncthreads();
+  for (int idx = (int)blockIdx.x;;) {
+    int tid1 = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid1));
+    __builtin_assume(tid1 >= 0 && tid1 < 64 * NW);
+    engine_item<C, false>(idx, tid1, S, P);
+    if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.wk_qhead, 1);
+    __syncthreads();
+    idx = S.qnext;
+    if (idx >= nitems) break;  // uniform
+  }
+}
+
+namespace {
+template <int RE, int KQ, int SQ, int NW, int MAXL, int MAXE>
+struct EngineEntry {
+  using C = ECfg<RE, KQ, SQ, NW, MAXL, MAXE>;
+  static hipError_t prepare() {
+    return hipFuncSetAttribute((const void*)qmpc_engine_kernel<RE, KQ, SQ, NW, MAXL, MAXE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sizeof(ESmem<C>));
+  }
+  static int resident() {
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, qmpc_engine_kernel<RE, KQ, SQ, NW, MAXL, MAXE>, 64 * NW,
+                                                                      sizeof(ESmem<C>));
+    if (e != hipSuccess || per < 1 || cus < 1) return 0;
+    return cached = per * cus;
+  }
+  static hipError_t launch(const QmpcParams* P, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL((qmpc_engine_kernel<RE, KQ, SQ, NW, MAXL, MAXE>), dim3(grid), dim3(64 * NW), sizeof(ESmem<C>), stream, *P);
+    return hipGetLastError();
+  }
+};
+// engine of the 128-row class: 2 row blocks, 64 working slots, 64 stance slots; 3 holders x 26 events (6 VGPRs per event;
+// 256 VGPRs per lane at two waves per SIMD, ~100 of them for everything else)
+typedef EngineEntry<2, 1, 1, 4, 24, 40> Engine2;
+// engine of the 192-row class: 3 row blocks, 128 working slots (all four feet down at horizon 14 / 16 ends with 70-90 rows at
+// a bound when braking): 10 VGPRs per event, 7 holders x 15 + 24 in LDS
+typedef EngineEntry<3, 2, 1, 8, 14, 24> Engine3;
+}  // namespace
+
+extern "C" hipError_t qmpc_engine_prepare(void) {
+  hipError_t e = Engine2::prepare();
+  if (e != hipSuccess) return e;
+  return Engine3::prepare();
+}
+extern "C" int qmpc_engine_resident(int rb) { return rb == 2 ? Engine2::resident() : (rb == 3 ? Engine3::resident() : 0); }
+extern "C" int qmpc_engine_capacity(int rb) { return rb == 2 ? Engine2::C::KEV : (rb == 3 ? Engine3::C::KEV : 0); }
+extern "C" hipError_t qmpc_engine_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
+  if (rb == 2) return Engine2::launch(P, grid, stream);
+  if (rb == 3) return Engine3::launch(P, grid, stream);
+  return hipErrorInvalidValue;
+}

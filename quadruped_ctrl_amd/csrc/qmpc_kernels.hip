@@ -50,18 +50,9 @@
 
 #include "qmpc_device.h"
 #include "qmpc_cmd.h"
+#include "qmpc_wave.h"
 
 namespace {
-typedef __attribute__((address_space(1))) double GlobalF64;  // a double known to live in global memory (global_load, not flat_load)
-typedef double __attribute__((ext_vector_type(2))) F64x2;
-typedef __attribute__((address_space(1))) F64x2 GlobalF64x2;
-// two adjacent doubles with one 16-byte access (p 16-byte aligned)
-__device__ __forceinline__ F64x2 ld2(const double* p) { return *reinterpret_cast<const F64x2*>(p); }
-__device__ __forceinline__ F64x2 ld2(const GlobalF64* p) { return *reinterpret_cast<const GlobalF64x2*>(p); }
-__device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<F64x2*>(p) = F64x2{a, b}; }
-__device__ __forceinline__ void st2(GlobalF64* p, double a, double b) { *reinterpret_cast<GlobalF64x2*>(p) = F64x2{a, b}; }
-
-constexpr int WAVE = 64;
 #ifndef QMPC_ENGINE_PRIO
 #define QMPC_ENGINE_PRIO 3
 #endif
@@ -71,103 +62,6 @@ constexpr int WAVE = 64;
 #ifndef QMPC_START_PRIO
 #define QMPC_START_PRIO 1
 #endif
-
-// ----------------------------------------------------------------- wave helpers
-// DPP control words (gfx9): row_shr:n = 0x110+n, row_bcast:15 = 0x142,
-// row_bcast:31 = 0x143.  After the six steps lane 63 holds the reduction.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-// max over the 64 lanes of a wave, result uniform
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  unsigned t;
-  t = dpp_u32<0x111, 0xf>(0u, v); v = v > t ? v : t;
-  t = dpp_u32<0x112, 0xf>(0u, v); v = v > t ? v : t;
-  t = dpp_u32<0x114, 0xf>(0u, v); v = v > t ? v : t;
-  t = dpp_u32<0x118, 0xf>(0u, v); v = v > t ? v : t;
-  t = dpp_u32<0x142, 0xa>(0u, v); v = v > t ? v : t;
-  t = dpp_u32<0x143, 0xc>(0u, v); v = v > t ? v : t;
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-// min over the 64 lanes of a wave, result uniform
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-  unsigned t;
-  t = dpp_u32<0x111, 0xf>(~0u, v); v = v < t ? v : t;
-  t = dpp_u32<0x112, 0xf>(~0u, v); v = v < t ? v : t;
-  t = dpp_u32<0x114, 0xf>(~0u, v); v = v < t ? v : t;
-  t = dpp_u32<0x118, 0xf>(~0u, v); v = v < t ? v : t;
-  t = dpp_u32<0x142, 0xa>(~0u, v); v = v < t ? v : t;
-  t = dpp_u32<0x143, 0xc>(~0u, v); v = v < t ? v : t;
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-// min over the wave of NON-NEGATIVE doubles (bit pattern order == value order):
-// two 32-bit reductions (high words, then the low words of the lanes that tie on
-// the high word) instead of one 64-bit compare/select ladder
-__device__ __forceinline__ double wave_min_pos_f64(double x) {
-  const unsigned long long v = (unsigned long long)__double_as_longlong(x);
-  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-  const unsigned mhi = wave_min_u32(hi);
-  const unsigned mlo = wave_min_u32(hi == mhi ? lo : ~0u);
-  return __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
-}
-// max over the wave of NON-NEGATIVE doubles: the min reduction on the bitwise complement (larger
-// value <=> smaller complement)
-__device__ __forceinline__ double wave_max_pos_f64(double x) {
-  const unsigned long long v = ~(unsigned long long)__double_as_longlong(x);
-  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-  const unsigned mhi = wave_min_u32(hi);
-  const unsigned mlo = wave_min_u32(hi == mhi ? lo : ~0u);
-  return __longlong_as_double((long long)~(((unsigned long long)mhi << 32) | mlo));
-}
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-// element q (uniform) of a small per-lane register array without dynamic indexing
-template <int KW, typename T>
-__device__ __forceinline__ T pick(const T (&arr)[KW], int q) {
-  T v = arr[0];
-#pragma unroll
-  for (int k = 1; k < KW; ++k) v = (q == k) ? arr[k] : v;
-  return v;
-}
-// element idx (wave-uniform) of a vector stored 64 entries per register: arr[idx >> 6] at lane
-// idx & 63.  One readlane per register and a scalar select -- a select over the REGISTERS would be
-// turned into a dynamically indexed private array (scratch) by the compiler
-template <int KW>
-__device__ __forceinline__ double lane_elem(const double (&arr)[KW], int idx) {
-  const int q = idx >> 6, l = idx & 63;
-  double out = readlane_f64(arr[0], l);
-#pragma unroll
-  for (int k = 1; k < KW; ++k) {
-    const double t = readlane_f64(arr[k], l);
-    out = (q == k) ? t : out;
-  }
-  return out;
-}
-template <int KW>
-__device__ __forceinline__ int lane_elem(const int (&arr)[KW], int idx) {
-  const int q = idx >> 6, l = idx & 63;
-  int out = __builtin_amdgcn_readlane(arr[0], l);
-#pragma unroll
-  for (int k = 1; k < KW; ++k) {
-    const int t = __builtin_amdgcn_readlane(arr[k], l);
-    out = (q == k) ? t : out;
-  }
-  return out;
-}
-// 1/d to full double precision: v_rcp_f64 seed + two Newton steps
-__device__ __forceinline__ double fast_rcp(double d) {
-  double x = __builtin_amdgcn_rcp(d);
-  double e = __builtin_fma(-d, x, 1.0);
-  x = __builtin_fma(x, e, x);
-  e = __builtin_fma(-d, x, 1.0);
-  x = __builtin_fma(x, e, x);
-  return x;
-}
 
 // a[j] += c[lane j of this lane's row of 16] * u for j = 0..15: sixteen DP-ALU DPP
 // fmacs (row_newbcast), i.e. the 16 wave-uniform pivot-column values are held one
@@ -228,48 +122,6 @@ __device__ __forceinline__ void fmac8_rowbcast(double (&a)[8], double c, double 
       : "v"(c), "v"(u));
 }
 
-// compile-time loop: f(integral_constant<int, R>) for R = 0 .. N-1, so that
-// register-array indices derived from R are constant expressions
-template <int R, int N>
-struct StaticFor {
-  template <class F>
-  static __device__ __forceinline__ void run(F&& f) {
-    f(std::integral_constant<int, R>{});
-    StaticFor<R + 1, N>::run(f);
-  }
-};
-template <int N>
-struct StaticFor<N, N> {
-  template <class F>
-  static __device__ __forceinline__ void run(F&&) {}
-};
-
-__device__ __forceinline__ int sym_idx(int a, int b) {
-  const int hi = a > b ? a : b, lo = a > b ? b : a;
-  return hi * (hi + 1) / 2 + lo;
-}
-
-// Constraint e = 5*slot + ty on stance slot `slot` (reduced vars 3*slot..+2):
-//   ty 0:  fx/mu + fz >= 0     ty 1: -fx/mu + fz >= 0
-//   ty 2:  fy/mu + fz >= 0     ty 3: -fy/mu + fz >= 0
-//   ty 4: -fz >= -fmax_k
-// (fmat / U_b of SolverMPC.cpp:352-378; the BIG_NUMBER uppers can never be
-//  active and fz >= 0 is implied by rows 0+1, so neither is instantiated.)
-// As a sparse row c = a1 e_{j1} + a2 e_{j2}:
-__device__ __forceinline__ void con_coefs(int e, double mi, int& j1, int& j2, double& a1, double& a2) {
-  const int slot = e / 5, ty = e - 5 * slot, j0 = 3 * slot;
-  j2 = j0 + 2;
-  if (ty < 4) {
-    j1 = j0 + (ty >> 1);
-    a1 = (ty & 1) ? -mi : mi;
-    a2 = 1.0;
-  } else {
-    j1 = j0 + 2;
-    a1 = -1.0;
-    a2 = 0.0;
-  }
-}
-
 // Size classes.  RB names the class: 1, 2, 3 = 64 / 128 / 192 padded rows (four column
 // groups of 16 RB columns, 256 RB threads); 4 = the 96-row class between 1 and 2 (four
 // groups of 24 columns, 384 threads, two workgroups per CU) that catches n_r <= 96 --
@@ -317,6 +169,12 @@ struct Cfg {
 #endif
   static constexpr int HELP_MIN_TRIPS = QMPC_HELP_MIN_TRIPS;
   static constexpr int MIN_WAVES = (RB == 1 || RB == 4) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
+  // ... of the producer half of the decoupled path (qmpc_sweep_kernel): without the packed inverse its LDS is the
+  // assembly / sweep storage only, so the 128-row class fits two workgroups per CU if it stays within 128 VGPRs
+#ifndef QMPC_SWEEP_WAVES2
+#define QMPC_SWEEP_WAVES2 4
+#endif
+  static constexpr int MIN_WAVES_A = (RB == 2) ? QMPC_SWEEP_WAVES2 : MIN_WAVES;
 };
 
 template <int RB>
@@ -391,7 +249,11 @@ struct Smem {
 // sum of rank-1 events; fastest, capacity-limited by the LDS pool), false = the
 // Schur form that never overflows.  Both are run by wave 0 alone.  Returns true
 // when the robot must be re-run with the other engine.
-template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false>
+// PHA = true: the PRODUCER half of the decoupled path (qmpc_sweep_kernel): stages 0-3 and the unconstrained
+// minimiser as below, then the inverse goes to the robot's work item in global memory (L2 / Infinity-Cache
+// resident) instead of LDS and the workgroup moves on; the active set is run by qmpc_engine_kernel
+// (qmpc_engine.hip) -- a workgroup of the large classes no longer pins a whole CU while one of its waves iterates.
+template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false, bool PHA = false>
 __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
@@ -698,6 +560,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     return false;
   }
   const double alpha = (double)g_alpha;
+  if constexpr (PHA) {
+    if (tid == 0) S.evslot = atomicAdd(P.wk_count, 1);  // this robot's work item (read after barrier 2)
+  }
   // ------------------------------------------------------------ stage 1
   // E_00 = B0^T W B0, E_11 = B1^T W B1 in closed form, and the weighted sums
   // s_p[st] = sum_{k>=st} coef_p(k-st) e_k.
@@ -1172,6 +1037,32 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     Sw.part[c][i] = acc;
   }
   __syncthreads();
+  if constexpr (PHA) {
+    // ---- producer: H^-1 (= -a) row i, columns of this thread's group -> the work item, full rows (the padding is the
+    // identity), 16-byte stores; x_u; the stance list.  Row-major and symmetric: the engine reads COLUMN j as row j,
+    // two or three coalesced loads.
+    const int item = S.evslot;
+    constexpr int LD = NP;
+    GlobalF64* const Hrow = (GlobalF64*)P.wk_hinv + (size_t)item * (LD * LD) + (size_t)i * LD + c * CW;
+#pragma unroll
+    for (int jj = 0; jj < CW; jj += 2) st2(Hrow + jj, -a[jj], -a[jj + 1]);
+    if (tid < NP)
+      P.wk_xu[(size_t)item * LD + tid] = (tid < n) ? Sw.part[0][tid] + Sw.part[1][tid] + Sw.part[2][tid] + Sw.part[3][tid] : 0.0;
+    QmpcWorkHdr* const hd = P.wk_hdr + item;
+    if (tid < 64) {
+      hd->sidx[tid] = S.sidx[tid];
+      hd->fmaxk[tid] = (tid < nst) ? (float)S.fmaxk[tid] : 0.f;
+    }
+    if (tid == 0) {
+      hd->rid = rid;
+      hd->n = n;
+      hd->nst = nst;
+      hd->status0 = S.status;
+    }
+    QMPC_TICK(5);
+    __syncthreads();  // (the next robot of a list-consuming workgroup reuses the LDS)
+    return false;
+  }
   const bool engine = tid < WAVE;
   double xv[RE];  // engine lane: x[lane + 64 q]
 #pragma unroll
@@ -2539,6 +2430,8 @@ __device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<R
   } else {
     solve_one<RB, false, CMD, false, WARM>(rid, tid, S, P);
   }
+  // (thread 0 wrote the robot's status; the launch that re-solves what the decoupled engine handed back says so)
+  if (P.status_or != 0 && tid == 0) P.status[rid] |= P.status_or;
 }
 
 // class 3: take a slice of the global event pool for the lifetime of the workgroup: slot = workgroup index
@@ -2591,7 +2484,7 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   if constexpr (!LISTED) {
     // (block index first: only block 0 waits for the kernel argument)
-    if (blockIdx.x == 0 && threadIdx.x < 8 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // 3 counters + 3 heads
+    if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // 3 counters + 3 heads
     pool_acquire<RB>(S, P);
     solve_robot<RB, CMD, WARM>((int)blockIdx.x, (int)threadIdx.x, S, P);
     pool_release<RB>(S, P);
@@ -2637,7 +2530,7 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_admm_ker
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   if constexpr (!LISTED) {
-    if (blockIdx.x == 0 && threadIdx.x < 8 && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
     solve_one<RB, false, false, true>((int)blockIdx.x, (int)threadIdx.x, S, P);
   } else {  // list = queue, as in qmpc_solve_kernel
     const int nlist = *P.count;
@@ -2657,7 +2550,43 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_admm_ker
   }
 }
 
+// Producer half of the decoupled path (classes 2 and 3): assembly, sweep, x_u, inverse -> work item.  Same launch
+// geometry rules as qmpc_solve_kernel (first of the chain: robot = blockIdx.x; LISTED: the list as a queue).
+template <int RB, bool CMD, bool LISTED = false>
+__global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES_A) void qmpc_sweep_kernel(const QmpcParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
+  Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  if constexpr (!LISTED) {
+    if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+    solve_one<RB, true, CMD, false, false, true>((int)blockIdx.x, (int)threadIdx.x, S, P);
+  } else {
+    const int nlist = *P.count;
+    if ((int)blockIdx.x >= nlist) return;  // uniform
+    for (int idx = (int)blockIdx.x;;) {
+      const int rid = P.list[idx];
+      int tid1 = (int)threadIdx.x;
+      asm volatile("" : "+v"(tid1));
+      __builtin_assume(tid1 >= 0 && tid1 < Cfg<RB>::NT);
+      typedef const __attribute__((address_space(4))) QmpcParams* KernargPtr;
+      KernargPtr pk = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(pk));
+      const QmpcParams& PK = *(const QmpcParams*)pk;
+      solve_one<RB, true, CMD, false, false, true>(rid, tid1, S, PK);
+      __syncthreads();
+      if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+      __syncthreads();
+      idx = S.qnext;
+      if (idx >= nlist) break;  // uniform
+    }
+  }
+}
+
 namespace {
+// LDS of the producer: everything but the active-set storage
+template <int RB>
+constexpr size_t sweep_smem() {
+  return sizeof(Smem<RB>) - sizeof(typename Smem<RB>::U) + sizeof(typename Smem<RB>::U::AW);
+}
 template <typename K>
 hipError_t set_smem(K kernel, size_t bytes) {
   return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -2676,7 +2605,44 @@ hipError_t prepare_class() {
     if ((e = set_smem(qmpc_solve_kernel<RB, false, true, true>, n)) != hipSuccess) return e;
     if ((e = set_smem(qmpc_admm_kernel<RB, true>, n)) != hipSuccess) return e;
   }
+  if constexpr (RB == 2 || RB == 3) {
+    const size_t na = sweep_smem<RB>();
+    if ((e = set_smem(qmpc_sweep_kernel<RB, false, false>, na)) != hipSuccess) return e;
+    if ((e = set_smem(qmpc_sweep_kernel<RB, true, false>, na)) != hipSuccess) return e;
+    if ((e = set_smem(qmpc_sweep_kernel<RB, false, true>, na)) != hipSuccess) return e;
+    if ((e = set_smem(qmpc_sweep_kernel<RB, true, true>, na)) != hipSuccess) return e;
+  }
   return hipSuccess;
+}
+template <int RB>
+void launch_sweep(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
+  if constexpr (RB == 2 || RB == 3) {
+    const dim3 g(grid), b(Cfg<RB>::NT);
+    const size_t n = sweep_smem<RB>();
+    if (P->list) {
+      if (cmd) hipLaunchKernelGGL((qmpc_sweep_kernel<RB, true, true>), g, b, n, stream, *P);
+      else hipLaunchKernelGGL((qmpc_sweep_kernel<RB, false, true>), g, b, n, stream, *P);
+    } else {
+      if (cmd) hipLaunchKernelGGL((qmpc_sweep_kernel<RB, true, false>), g, b, n, stream, *P);
+      else hipLaunchKernelGGL((qmpc_sweep_kernel<RB, false, false>), g, b, n, stream, *P);
+    }
+  }
+}
+template <int RB>
+int resident_sweep() {
+  if constexpr (RB == 2 || RB == 3) {
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, qmpc_sweep_kernel<RB, false, true>, Cfg<RB>::NT,
+                                                                      sweep_smem<RB>());
+    if (e != hipSuccess || per < 1 || cus < 1) return 0;
+    return cached = per * cus;
+  } else {
+    return 0;
+  }
 }
 template <int RB, bool LISTED>
 void launch_variant(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
@@ -2724,6 +2690,11 @@ int resident_class() {
   extern "C" int qmpc_c##RB##_resident(void) { return resident_class<RB>(); }                              \
   extern "C" hipError_t qmpc_c##RB##_launch(const QmpcParams* P, int grid, hipStream_t stream) {           \
     launch_one<RB>(P->c_position != nullptr, P, grid, stream);                                             \
+    return hipGetLastError();                                                                              \
+  }                                                                                                        \
+  extern "C" int qmpc_c##RB##_resident_sweep(void) { return resident_sweep<RB>(); }                        \
+  extern "C" hipError_t qmpc_c##RB##_launch_sweep(const QmpcParams* P, int grid, hipStream_t stream) {     \
+    launch_sweep<RB>(P->c_position != nullptr, P, grid, stream);                                           \
     return hipGetLastError();                                                                              \
   }
 #if !defined(QMPC_RB) || QMPC_RB == 1

@@ -801,6 +801,7 @@ def test_event_pool_overflow_continues_in_global_memory(mk, name, mpc_factory):
     same QP, and the Schur-form engine is not needed for it."""
     b = mk()
     m = mpc_factory(b)
+    m.set_split(False)   # the one-kernel path owns the overflow pool (the decoupled engine keeps its events in registers)
     res, idx, worst, _ = _solver_parity_on_own_qp(m, b, lambda r: np.nonzero(r["status"] & 128)[0][:6])
     print(name, "spilled robots", int(((res["status"] & 128) != 0).sum()), "checked", len(idx), "worst err", worst,
           "fallback", int(((res["status"] & 16) != 0).sum()))
@@ -818,6 +819,7 @@ def test_overflow_pool_exhausted_falls_back(mpc_factory):
     with all slices, and every call starts with all slices free again."""
     b = W.make_standing(1024, 10)
     m = mpc_factory(b)
+    m.set_split(False)   # (one-kernel path: see above)
     base = m.solve(b, full=True)
     sp = np.nonzero(base["status"] & 128)[0]
     assert len(sp) >= 4 and not (base["status"] & 16).any() and ((base["status"] & 47) == 0).all()
@@ -832,6 +834,51 @@ def test_overflow_pool_exhausted_falls_back(mpc_factory):
         rest = np.setdiff1d(np.arange(1024), sp)
         assert np.array_equal(cut["soln"][rest], base["soln"][rest])
     m.debug_overflow_slices(-1)
+    assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+
+
+@pytest.mark.parametrize("mk,name", [(lambda: W.make_standing(300, 10), "standing h10"), (lambda: W.make_standing(260, 14), "standing h14"),
+                                     (lambda: W.make_standing(200, 16), "standing h16"),
+                                     (lambda: W.shard(W.make_config(4, batch=8 * 1024), 0, 8), "configs[4] shard")])
+def test_decoupled_path_matches_one_kernel_path_and_qpoases(mk, name, mpc_factory):
+    """the 128- / 192-row classes solved by sweep kernel -> work item -> engine kernel (events in the holder
+    waves' registers) against (a) the one-kernel path on the same robots and (b) the reference's qpOASES on the GPU's
+    own H_red, g_red for the robots with the longest active-set runs.  Repeated calls are bit-identical."""
+    b = mk()
+    m = mpc_factory(b)
+    m.set_split(False)
+    one = m.solve(b, full=True)
+    m.set_split(True)
+    res, idx, worst, nact = _solver_parity_on_own_qp(m, b, lambda r: np.argsort(r["iters"])[-4:])
+    assert ((one["status"] & 47) == 0).all() and ((res["status"] & 47) == 0).all()
+    scale = np.abs(one["soln"]).max(1).clip(1.0)
+    d = (np.abs(res["soln"] - one["soln"]).max(1) / scale).max()
+    print(name, "decoupled vs one-kernel", d, "vs qpOASES on own QP", worst, "iters", res["iters"][idx].tolist(), "rows at a bound", nact,
+          "handed back", int(((res["status"] & 16) != 0).sum()))
+    assert d < 1e-10
+    assert abs(float(res["iters"].mean()) - float(one["iters"].mean())) < 0.5
+    for _ in range(2):
+        again = m.solve(b, full=True)
+        assert np.array_equal(again["soln"], res["soln"]) and np.array_equal(again["status"], res["status"])
+
+
+def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
+    """The engine kernel keeps the rank-1 events in registers / LDS: a robot that needs more of them than fit is handed
+    back through a list and solved from scratch by the one-kernel path in the same call (status bit 16), same answer.
+    Test hook: the capacity cut to 12 events."""
+    b = W.make_standing(200, 10)
+    m = mpc_factory(b)
+    base = m.solve(b, full=True)
+    assert ((base["status"] & 47) == 0).all() and not (base["status"] & 16).any()
+    m.set_debug_engine_events(12)
+    cut = m.solve(b, full=True)
+    m.set_debug_engine_events(0)
+    assert ((cut["status"] & 47) == 0).all()
+    back = (cut["status"] & 16) != 0
+    assert back.sum() > 50 and (base["iters"][back] >= 12).all() and (base["iters"][~back] <= 12).all()
+    scale = np.abs(base["soln"]).max(1).clip(1.0)
+    assert (np.abs(cut["soln"] - base["soln"]).max(1) / scale).max() < 1e-9
+    assert np.array_equal(cut["soln"][~back], base["soln"][~back])
     assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
 
 
