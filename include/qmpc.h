@@ -184,6 +184,19 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
  * one-kernel path.  off: the one-kernel path for every class (QMPC_NO_SPLIT=1 in the environment selects that
  * at qmpc_create).  The JCQP alternate and warm-started solves always take the one-kernel path. */
 int qmpc_set_split(qmpc_handle h, int on);
+/* Block start of the decoupled path's engine -- EXPERIMENTAL, default off.  The rows of the friction pyramids / force
+ * limits that are violated at the unconstrained minimiser are, almost without exception, active at the solution; with
+ * on != 0 the engine adds such candidate sets (one row per stance foot-step and round, up to four rounds) as forced
+ * additions made by all threads of the workgroup with the records in LDS, removes the rows whose multiplier came out
+ * negative and hands a valid Goldfarb-Idnani state to the normal iteration.  Same unique minimiser (tested), but as
+ * measured on MI355X not faster than the iteration it replaces: ~3.1 k cycles per forced change against
+ * ~4.9 k per iteration, and 20 % more changes.  `iters` counts every forced change like an iteration. */
+int qmpc_set_block_start(qmpc_handle h, int on);
+/* Chunks of the decoupled path: the robots of such a class are processed as n consecutive chunks whose sweep and engine
+ * kernels are enqueued on the handle's own auxiliary streams (a chunk's active set runs beside the next chunk's sweep)
+ * and joined into the caller's stream before the call returns control of it.  0 (default) = chosen by batch size
+ * (1 below 192 robots ... 8 from 2048), 1 = everything on the caller's stream, at most 8.  Results do not depend on it. */
+int qmpc_set_chunks(qmpc_handle h, int n);
 /* Allocate now whatever the current setup and stance hints can need later (the decoupled path's work items), so
  * that no solve call allocates -- call it before capturing solves into a graph. */
 int qmpc_reserve(qmpc_handle h);

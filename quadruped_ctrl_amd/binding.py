@@ -25,7 +25,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
            "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
-           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events"]
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
@@ -103,6 +103,8 @@ def load_library():
         lib.qmpc_set_split.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_reserve.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_engine_events.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_chunks.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_block_start.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.qmpc_set_model.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_kf_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -468,6 +470,12 @@ class BatchedConvexMPC:
     def set_split(self, on):
         """Decoupled sweep / engine kernels for the 128- and 192-row classes (default on)."""
         self._check(self.lib.qmpc_set_split(self.h, int(bool(on))), "qmpc_set_split")
+
+    def set_block_start(self, on):
+        self._check(self.lib.qmpc_set_block_start(self.h, int(bool(on))), "qmpc_set_block_start")
+
+    def set_chunks(self, n):
+        self._check(self.lib.qmpc_set_chunks(self.h, int(n)), "qmpc_set_chunks")
 
     def set_debug_engine_events(self, n):
         self._check(self.lib.qmpc_set_debug_engine_events(self.h, int(n)), "qmpc_set_debug_engine_events")

@@ -109,6 +109,12 @@ struct qmpc_ctx {
   QmpcWorkHdr* d_wk_hdr[2] = {nullptr, nullptr};
   int wk_cap[2] = {0, 0};
   int* d_fb_lists = nullptr;   // [2][max_batch] robots the engine kernels hand back
+  // chunked launches of the decoupled path: sweep kernels of consecutive chunks on aux[0], engine kernels alternating
+  // on aux[1] / aux[2], so that a chunk's active set runs beside the next chunk's sweep; joined into the caller's stream
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_chunk[QMPC_MAX_CHUNKS] = {}, ev_join[3] = {nullptr, nullptr, nullptr};
+  bool block = false;          // qmpc_set_block_start (experimental, off: measured no faster); QMPC_BLOCK=1 in the environment switches it on at creation
+  int chunks = 0;              // qmpc_set_chunks: 0 = automatic (by batch size), 1 = no chunking
   int dbg_engine_events = 0;   // test hook: events the engine may hold per robot (0 = the compiled capacity)
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
@@ -214,6 +220,8 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = !(ns && ns[0] == '1');
+    const char* nb = std::getenv("QMPC_BLOCK");
+    c->block = nb && nb[0] == '1';
   }
   if (e == hipSuccess) {
     // a robot whose on-chip event pool fills up continues here; more than ov_nslice of them in one launch chain
@@ -242,6 +250,13 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_ovpool) hipFree(h->d_ovpool);
     if (h->d_evflags) hipFree(h->d_evflags);
     if (h->d_fb_lists) hipFree(h->d_fb_lists);
+    for (int k = 0; k < 3; ++k) {
+      if (h->aux[k]) hipStreamDestroy(h->aux[k]);
+      if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
+    }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    for (int k = 0; k < QMPC_MAX_CHUNKS; ++k)
+      if (h->ev_chunk[k]) hipEventDestroy(h->ev_chunk[k]);
     for (int k = 0; k < 2; ++k) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
@@ -400,6 +415,18 @@ int qmpc_set_split(qmpc_handle c, int on) {
   return QMPC_OK;
 }
 
+int qmpc_set_block_start(qmpc_handle c, int on) {
+  if (!c) return QMPC_ERR_ARG;
+  c->block = on != 0;
+  return QMPC_OK;
+}
+
+int qmpc_set_chunks(qmpc_handle c, int n) {
+  if (!c || n < 0 || n > QMPC_MAX_CHUNKS) return QMPC_ERR_ARG;
+  c->chunks = n;
+  return QMPC_OK;
+}
+
 int qmpc_set_debug_engine_events(qmpc_handle c, int n) {
   if (!c || n < 0) return QMPC_ERR_ARG;
   c->dbg_engine_events = n;
@@ -464,6 +491,17 @@ int ensure_split(qmpc_ctx* c, int rb) {
   HIP_TRY(c, hipMalloc(&c->d_wk_xu[k], sizeof(double) * cap * ld));
   HIP_TRY(c, hipMalloc(&c->d_wk_hdr[k], sizeof(QmpcWorkHdr) * cap));
   c->wk_cap[k] = (int)cap;
+  return QMPC_OK;
+}
+
+int ensure_aux(qmpc_ctx* c) {
+  if (c->aux[0]) return QMPC_OK;
+  for (int k = 0; k < 3; ++k) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
+  }
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  for (int k = 0; k < QMPC_MAX_CHUNKS; ++k) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
   return QMPC_OK;
 }
 
@@ -597,30 +635,62 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       A.wk_hinv = c->d_wk_hinv[sk];
       A.wk_xu = c->d_wk_xu[sk];
       A.wk_hdr = c->d_wk_hdr[sk];
-      A.wk_count = cnt + 8 + sk;
-      A.wk_qhead = cnt + 10 + sk;
       A.wk_ld = chain[k] == 2 ? 128 : 192;
       A.wk_cap = c->wk_cap[sk];
       A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
+      A.wk_block = c->block ? 1 : 0;
       A.fb_list = c->d_fb_lists + (size_t)sk * c->max_batch;
       A.fb_count = cnt + 12 + sk;
-      int grid = batch;
-      if (listed) {
-        const int res = qmpc_resident_sweep(chain[k]);
-        if (res > 0 && res < grid) grid = res;
+      // chunks of consecutive robots (list entries): the sweep kernels run one after the other on one auxiliary stream, every
+      // chunk's engine kernel on another as soon as ITS sweep is done -- beside the next chunk's sweep.  A launch ends
+      // with its slowest robot (60+ iterations when braking): the more chunks, the less of the batch waits behind it
+      int nch = c->chunks > 0 ? c->chunks : 1;
+      if (nch > QMPC_MAX_CHUNKS) nch = QMPC_MAX_CHUNKS;
+      const int per = (batch + nch - 1) / nch;
+      if (nch > 1) {
+        if (const int rc = ensure_aux(c)) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_fork, stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
       }
-      HIP_TRY(c, qmpc_launch_sweep(chain[k], &A, grid, stream));
-      QmpcParams B = A;  // the engine: one robot per workgroup, the items as a queue
-      B.list = nullptr; B.count = nullptr; B.qhead = nullptr; B.clear_counts = nullptr;
-      B.next_list = nullptr; B.next_count = nullptr;
-      int gb = batch;
-      {
-        const int res = qmpc_engine_resident(chain[k]);
-        if (res > 0 && res < gb) gb = res;
+      for (int ch = 0; ch < nch; ++ch) {
+        const int lo = ch * per, hi = (lo + per < batch) ? lo + per : batch;
+        if (lo >= hi) break;
+        hipStream_t sa = nch > 1 ? c->aux[0] : stream, sb = nch > 1 ? c->aux[1 + (ch & 1)] : stream;
+        A.wk_count = cnt + 16 + 8 * sk + ch;
+        A.wk_qhead = cnt + 32 + 8 * sk + ch;
+        A.wk_base = lo;
+        A.rid0 = lo;
+        A.list_hi = hi;
+        A.qhead = listed ? cnt + 48 + 8 * sk + ch : nullptr;
+        A.clear_counts = (!listed && ch == 0) ? cnt_next : nullptr;
+        int grid = hi - lo;
+        if (listed) {
+          const int res = qmpc_resident_sweep(chain[k]);
+          if (res > 0 && res < grid) grid = res;
+        }
+        HIP_TRY(c, qmpc_launch_sweep(chain[k], &A, grid, sa));
+        if (nch > 1) {
+          HIP_TRY(c, hipEventRecord(c->ev_chunk[ch], sa));
+          HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_chunk[ch], 0));
+        }
+        QmpcParams B = A;  // the engine: one robot per workgroup, the chunk's items as a queue
+        B.list = nullptr; B.count = nullptr; B.qhead = nullptr; B.clear_counts = nullptr;
+        B.next_list = nullptr; B.next_count = nullptr;
+        int gb = hi - lo;
+        {
+          const int res = qmpc_engine_resident(chain[k]);
+          if (res > 0 && res < gb) gb = res;
+        }
+        HIP_TRY(c, qmpc_engine_launch(chain[k], &B, gb, sb));
       }
-      HIP_TRY(c, qmpc_engine_launch(chain[k], &B, gb, stream));
+      if (nch > 1)
+        for (int a = 0; a < 3; ++a) {  // join: everything after this (hand-backs, the next class, the caller) sees all chunks
+          HIP_TRY(c, hipEventRecord(c->ev_join[a], c->aux[a]));
+          HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_join[a], 0));
+        }
       QmpcParams F = P;  // robots handed back (event capacity exceeded): the monolithic kernel, list-consuming
       F.list = A.fb_list; F.count = A.fb_count; F.qhead = cnt + 14 + sk; F.clear_counts = nullptr;
+      F.list_hi = 0x7fffffff;
       F.next_list = nullptr; F.next_count = nullptr;
       F.status_or = QMPC_DEV_ST_FALLBACK;
       if (chain[k] == 3 && c->d_evflags)

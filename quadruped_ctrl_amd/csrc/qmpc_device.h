@@ -27,7 +27,11 @@
 // kernel of a chain zeroes the NEXT call's set):  [0..2] list lengths of classes 4, 2, 3   [4..6] their queue heads
 // [7] overflow-pool slices handed out   [8,9] work items produced by the sweep kernels of classes 2, 3   [10,11] the
 // engine kernels' queue heads   [12,13] robots handed back to the monolithic kernels   [14,15] their queue heads
-#define QMPC_COUNTERS 16
+//   chunked launches of the decoupled path (sweep / engine kernels of consecutive robot ranges on separate streams, so
+//   that a chunk's active set runs beside the next chunk's sweep), split class sk = 0 (128 rows) / 1 (192 rows), chunk c < 8:
+//   [16 + 8 sk + c] work items produced   [32 + 8 sk + c] engine queue head   [48 + 8 sk + c] sweep kernel's list queue head
+#define QMPC_COUNTERS 64
+#define QMPC_MAX_CHUNKS 8
 
 // decoupled path: a sweep workgroup (or the long-horizon producer) leaves its robot's explicit inverse,
 // unconstrained minimiser and stance list in a work item; single-robot engine workgroups consume the items
@@ -101,6 +105,10 @@ struct QmpcParams {
   int* wk_count;
   int* wk_qhead;
   int wk_ld, wk_cap;
+  int wk_base;  // first work item of this launch's chunk (items wk_base .. wk_base + *wk_count - 1)
+  int rid0;     // sweep kernel: first robot (or list entry) of this launch's chunk
+  int list_hi;  // ... and one past its last list entry (list-consuming launches)
+  int wk_block;  // 1: the engine starts from a block-factorised candidate set (block_start, qmpc_engine.hip)
   int wk_kev;  // events the engine may hold per robot (test hook; the compiled capacity when larger)
   int* fb_list;
   int* fb_count;

@@ -45,6 +45,9 @@ struct ECfg {
   static constexpr int KEV = NH * MAXL + MAXE;    // capacity
   static constexpr int EV = NP + KS;
   static_assert(MAXE >= MAXL && MAXE <= 64, "engine-held events");
+  // block start: constraints factorised at once (their records M -> Z~ live in the engine wave's event pool; the
+  // Cholesky factor is held one row per lane of one wave, KB doubles per lane)
+  static constexpr int KB = (MAXE < 40 ? MAXE : 40) & ~1;
   static_assert(NSL <= QMPC_WK_SLOTS_MAX, "stance slots of a work item");
   static_assert(5 * NSL <= 1024, "constraint id in ten bits of the selection key");
 };
@@ -80,6 +83,17 @@ struct ESmem {
   double xl[C::NP];                      // x, variable-indexed, for the stance-slot lanes of the selection
   double D[C::NP];                       // diag(H^-1)
   float fb[12];
+  // block start (see block_start): working set and multipliers by slot, the signs of the records in the event pool
+  struct Blk {
+    int ne, nadd, nc, fail, dl, pad0, pad1, pad2;
+    int cand[C::NSL];          // this round's candidates (constraint ids)
+    int wcid[C::KS];           // working-set slot -> constraint id (-1 = free)
+    int sign[C::MAXE];         // record e: +1 add event, -1 drop event
+    unsigned bmask[C::NSL];    // stance slot -> rows in the working set
+    double lam[C::KS];         // multipliers by slot
+    alignas(16) double Y[C::MAXE];
+    alignas(16) double Ys[C::MAXE];
+  } bk;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over ALL address
@@ -120,6 +134,263 @@ __device__ __forceinline__ void dispatch_blocks(int q1, int q2, F&& f) {
   });
 }
 
+// ---------------------------------------------------------------------------------------------------- block start
+// The dual active set adds ONE constraint per iteration, and a robot braking to a stand ends with 30+ rows at a bound:
+// a serial chain of 30+ iterations of ~5 k cycles, each with a selection, a ratio test and two barrier rounds with the
+// holders.  Most of those rows are known early: the rows violated at the unconstrained minimiser x_u are, almost
+// without exception, active at the solution (precision 0.96 - 1.00).  So the iteration starts from a BLOCK
+// of forced additions, made by ALL threads of the workgroup with the records in LDS (the engine wave's event pool):
+//   round r = 1 .. QMPC_BLK_ROUNDS: the most violated row of every stance foot-step at the current x (not in W yet),
+//   each added as in a full Goldfarb-Idnani step but WITHOUT search and ratio test:
+//       y_e = z~_e^T c (thread e),  z = H^-1 c - sum_add y z~ + sum_drop y z~,  r = sum y g~  (thread per entry),
+//       delta = c^T z,  t = -(c^T x - rhs) / delta,  x += t z,  lambda_W -= t r,  lambda_p = t,  record (z, -r, 1) / sqrt(delta)
+//   -- ~0.8 k + 12 cycles per earlier record instead of ~5 k per iteration; x is then the minimiser on W as equalities;
+//   afterwards the rows whose multiplier came out negative leave, most negative first (drop records with the repair
+//   step: x -= (lambda_l / gamma) N*_l, lambda -= (lambda_l / gamma) S^-1[:, l]), again by all threads.
+// What comes out is a genuine Goldfarb-Idnani state (x optimal on W, multipliers >= 0, the projected inverse as rank-1
+// records): the holders take their share of the records into registers and the normal iteration finishes the job --
+// same unique minimiser (tools/block_proto.py: braking at horizon 10, 34 iterations -> 4 rounds, ~5 drops, ~4 iterations).
+#ifndef QMPC_BLK_ROUNDS
+#define QMPC_BLK_ROUNDS 4
+#endif
+template <class C>
+__device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const GlobalF64* const Hi, const GlobalF64* const xu,
+                                            const int n, const int nst, const int max_changes) {
+  constexpr int SQ = C::SQ, NP = C::NP, LD = C::NP, NT = C::NT, EV = C::EV, KS = C::KS, MAXE = C::MAXE;
+  constexpr int NCMAX = 12;  // candidates added per round
+  static_assert(EV <= NT, "one thread per record entry");
+  const QmpcParams& P = S.par;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto& B = S.bk;
+  double(*const R)[EV] = S.epool;  // record e: z~_e in [0, NP), g~_e in [NP, NP + KS)
+  double* const T = S.stage;       // the vector being built (z | r)
+  const double mi = P.mu_inv;
+  if (tid == 0) {
+    B.ne = 0;
+    B.nadd = 0;
+    B.fail = 0;
+  }
+  for (int k = tid; k < KS; k += NT) {
+    B.wcid[k] = -1;
+    B.lam[k] = 0.0;
+  }
+  __syncthreads();
+  const bool isvar = tid < NP, isslot = tid >= NP && tid < EV;
+  const int w = tid - NP;  // slot of a slot thread
+  // one accumulation over the records: acc += yv[e] * R[e][tid], four records per trip
+  auto accumulate = [&](const double* yv, int ne, double acc) __attribute__((always_inline)) {
+    // (eight records per trip, two partial sums: the loop is bound by LDS latency, not by its arithmetic)
+    int e = 0;
+    double acc2 = 0.0;
+#pragma unroll 1
+    for (; e + 8 <= ne; e += 8) {
+      const F64x2 ya = ld2(yv + e), yb = ld2(yv + e + 2), yc = ld2(yv + e + 4), yd = ld2(yv + e + 6);
+      const double r0 = R[e][tid], r1 = R[e + 1][tid], r2 = R[e + 2][tid], r3 = R[e + 3][tid];
+      const double r4 = R[e + 4][tid], r5 = R[e + 5][tid], r6 = R[e + 6][tid], r7 = R[e + 7][tid];
+      acc = __builtin_fma(ya.x, r0, acc);
+      acc2 = __builtin_fma(ya.y, r1, acc2);
+      acc = __builtin_fma(yb.x, r2, acc);
+      acc2 = __builtin_fma(yb.y, r3, acc2);
+      acc = __builtin_fma(yc.x, r4, acc);
+      acc2 = __builtin_fma(yc.y, r5, acc2);
+      acc = __builtin_fma(yd.x, r6, acc);
+      acc2 = __builtin_fma(yd.y, r7, acc2);
+    }
+    if (e + 4 <= ne) {
+      const F64x2 ya = ld2(yv + e), yb = ld2(yv + e + 2);
+      const double r0 = R[e][tid], r1 = R[e + 1][tid], r2 = R[e + 2][tid], r3 = R[e + 3][tid];
+      acc = __builtin_fma(ya.x, r0, acc);
+      acc2 = __builtin_fma(ya.y, r1, acc2);
+      acc = __builtin_fma(yb.x, r2, acc);
+      acc2 = __builtin_fma(yb.y, r3, acc2);
+      e += 4;
+    }
+    for (; e < ne; ++e) acc = __builtin_fma(yv[e], R[e][tid], acc);
+    return acc + acc2;
+  };
+  bool stop = false;
+  for (int round = 0; round < QMPC_BLK_ROUNDS && !stop; ++round) {
+    if (wv == 0) {
+      // ---- this round's candidates: the most violated row of every stance foot-step at the current x, not in W
+      const double inv_fr = P.inv_fr_norm, tol = P.tol;
+#pragma unroll
+      for (int s = 0; s < SQ; ++s) B.bmask[lane + 64 * s] = 0u;
+      __builtin_amdgcn_wave_barrier();
+      for (int k = lane; k < KS; k += 64) {
+        const int id = B.wcid[k];
+        if (id >= 0) atomicOr(&B.bmask[id / 5], 1u << (id % 5));
+      }
+      __builtin_amdgcn_wave_barrier();
+      int nc = 0;
+#pragma unroll
+      for (int s = 0; s < SQ; ++s) {
+        const int sl = lane + 64 * s;
+        const int sc = sl < nst ? sl : 0;
+        const double x0 = S.xl[3 * sc], x1 = S.xl[3 * sc + 1], x2 = S.xl[3 * sc + 2];
+        const unsigned am = B.bmask[sc];
+        const double fmx = (double)S.fmaxk[sc];
+        int tmin = -1;
+        if (sl < nst) {
+          const double fx = mi * x0, fy = mi * x1;
+          double vmin = 0.0;
+          const double sv[5] = {(fx + x2) * inv_fr, (x2 - fx) * inv_fr, (fy + x2) * inv_fr, (x2 - fy) * inv_fr, fmx - x2};
+#pragma unroll
+          for (int ty = 0; ty < 5; ++ty) {
+            const bool cand = !((am >> ty) & 1u) && sv[ty] < vmin;
+            vmin = cand ? sv[ty] : vmin;
+            tmin = cand ? ty : tmin;
+          }
+          if (!(vmin < -tol)) tmin = -1;
+        }
+        const unsigned long long vm = __ballot(tmin >= 0);
+        if (tmin >= 0) B.cand[nc + __popcll(vm & ((1ull << lane) - 1ull))] = 5 * sl + tmin;
+        nc += __popcll(vm);
+      }
+      if (lane == 0) B.nc = nc;
+    }
+    __syncthreads();
+    int nc = B.nc;
+    if (nc == 0) break;  // uniform: nothing violated (optimal) -- or nothing new to add
+    nc = nc < NCMAX ? nc : NCMAX;  // (the rest of a longer list is picked up by the next round)
+    // ---- H^-1 c for EVERY candidate of the round first: all loads in flight together, one L2 / HBM round trip per round
+    // (the inverse was written by another kernel: every column is a first touch, ~2 k cycles each if waited for singly)
+    double zc[NCMAX];
+    Upto<0, NCMAX>::run(nc, [&](auto cic) __attribute__((always_inline)) {
+      constexpr int ci = decltype(cic)::value;
+      const int id = B.cand[ci];
+      const int slot = id / 5, ty = id - 5 * slot, j0 = 3 * slot;
+      const int j1 = (ty < 4) ? j0 + (ty >> 1) : j0 + 2, j2 = j0 + 2;
+      const double a1 = (ty < 4) ? ((ty & 1) ? -mi : mi) : -1.0, a2 = (ty < 4) ? 1.0 : 0.0;
+      zc[ci] = (isvar && tid < n) ? __builtin_fma(a2, Hi[(size_t)j2 * LD + tid], a1 * Hi[(size_t)j1 * LD + tid]) : 0.0;
+    });
+    Upto<0, NCMAX>::run(nc, [&](auto cic) __attribute__((always_inline)) {
+      constexpr int ci = decltype(cic)::value;
+      if (stop) return;
+      const int ne = B.ne, q = B.nadd;
+      if (ne >= MAXE || q >= KS || ne >= max_changes) {  // uniform: no room / iteration limit -- the normal iteration goes on
+        stop = true;
+        return;
+      }
+      // ---- forced addition of row id into slot q
+      const int id = B.cand[ci];
+      const int slot = id / 5, ty = id - 5 * slot, j0 = 3 * slot;
+      const int j1 = (ty < 4) ? j0 + (ty >> 1) : j0 + 2, j2 = j0 + 2;
+      const double a1 = (ty < 4) ? ((ty & 1) ? -mi : mi) : -1.0, a2 = (ty < 4) ? 1.0 : 0.0;
+      const double rhs = (ty == 4) ? -(double)S.fmaxk[slot] : 0.0;
+      if (tid < ne) {
+        const double y = __builtin_fma(a2, R[tid][j2], a1 * R[tid][j1]);
+        B.Y[tid] = y;
+        B.Ys[tid] = (B.sign[tid] > 0) ? -y : y;
+      }
+      const double sp = __builtin_fma(a2, S.xl[j2], a1 * S.xl[j1]) - rhs;  // (x is stable until step 3)
+      lds_barrier();
+      if (isvar) T[tid] = accumulate(B.Ys, ne, zc[ci]);
+      else if (isslot) T[tid] = accumulate(B.Y, ne, 0.0);
+      lds_barrier();
+      const double delta = __builtin_fma(a2, T[j2], a1 * T[j1]);
+      const double cn = __builtin_fma(a2 * a2, S.D[j2], a1 * a1 * S.D[j1]);
+      if (delta > 1e-11 * cn) {  // uniform (else: the row depends on the ones in W, e.g. the pyramid's apex: skipped)
+        const double tt = -sp * fast_rcp(delta);
+        double sq = __builtin_amdgcn_rsq(delta);
+        {
+          double e = __builtin_fma(-delta * sq, sq, 1.0);
+          sq = __builtin_fma(0.5 * sq, e, sq);
+          e = __builtin_fma(-delta * sq, sq, 1.0);
+          sq = __builtin_fma(0.5 * sq, e, sq);
+        }
+        if (isvar) {
+          const double z = T[tid];
+          R[ne][tid] = z * sq;
+          if (tid < n) S.xl[tid] = __builtin_fma(tt, z, S.xl[tid]);
+        } else if (isslot) {
+          const double r = T[tid];
+          const bool active = B.wcid[w] >= 0;
+          R[ne][tid] = (w == q) ? sq : (active ? -r * sq : 0.0);
+          if (active) B.lam[w] = __builtin_fma(-tt, r, B.lam[w]);
+          if (w == q) {
+            B.lam[w] = tt;
+            B.wcid[w] = id;
+          }
+        }
+        if (tid == 0) {
+          B.sign[ne] = 1;
+          B.ne = ne + 1;
+          B.nadd = q + 1;
+        }
+      }
+      lds_barrier();
+    });
+  }
+  // ---- rows whose multiplier came out negative leave, most negative first
+  while (true) {
+    if (wv == 0) {
+      double worst = 0.0;
+      for (int k = lane; k < KS; k += 64) {
+        const double v = (B.wcid[k] >= 0 && B.lam[k] < 0.0) ? -B.lam[k] : 0.0;
+        worst = v > worst ? v : worst;
+      }
+      const double wmax = wave_max_pos_f64(worst);
+      int l = -1;
+      if (wmax > 0.0) {
+        for (int k0 = 0; k0 < KS && l < 0; k0 += 64) {
+          const int k = k0 + lane;
+          const unsigned long long hit = __ballot(B.wcid[k] >= 0 && B.lam[k] < 0.0 && -B.lam[k] == wmax);
+          if (hit != 0ull) l = k0 + __ffsll((long long)hit) - 1;
+        }
+      }
+      if (lane == 0) B.dl = l;
+    }
+    lds_barrier();
+    const int l = B.dl, ne = B.ne;
+    if (l < 0 || ne >= MAXE || ne >= max_changes) break;  // uniform (rows still negative are dropped by the engine wave's own loop)
+    if (tid < ne) {
+      const double y = R[tid][NP + l];
+      B.Y[tid] = y;
+      B.Ys[tid] = (B.sign[tid] > 0) ? y : -y;
+    }
+    const double laml = B.lam[l];
+    lds_barrier();
+    if (isvar) T[tid] = accumulate(B.Y, ne, 0.0);        // u = N*_l
+    else if (isslot) T[tid] = accumulate(B.Ys, ne, 0.0); // sc = S^-1[:, l]
+    lds_barrier();
+    const double gamma = T[NP + l];
+    if (!(gamma > 0.0)) {  // uniform: numerically lost S^-1[l][l] > 0 -- the robot is handed back
+      if (tid == 0) B.fail = 1;
+      break;
+    }
+    const double coef = laml * fast_rcp(gamma);
+    double sg = __builtin_amdgcn_rsq(gamma);
+    {
+      double e = __builtin_fma(-gamma * sg, sg, 1.0);
+      sg = __builtin_fma(0.5 * sg, e, sg);
+      e = __builtin_fma(-gamma * sg, sg, 1.0);
+      sg = __builtin_fma(0.5 * sg, e, sg);
+    }
+    if (tid < ne) R[tid][NP + l] = 0.0;  // slot l leaves: its column of every earlier g~ is cleared
+    if (isvar) {
+      const double u = T[tid];
+      R[ne][tid] = u * sg;
+      if (tid < n) S.xl[tid] = __builtin_fma(-coef, u, S.xl[tid]);
+    } else if (isslot) {
+      const double sc = T[tid];
+      const bool active = B.wcid[w] >= 0 && w != l;
+      R[ne][tid] = active ? -sc * sg : 0.0;
+      if (active) B.lam[w] = __builtin_fma(-coef, sc, B.lam[w]);
+      if (w == l) {
+        B.wcid[w] = -1;
+        B.lam[w] = 0.0;
+      }
+    }
+    if (tid == 0) {
+      B.sign[ne] = -1;
+      B.ne = ne + 1;
+    }
+    lds_barrier();
+  }
+  __syncthreads();
+}
+
 template <class C, bool WARM>
 __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem<C>& S, const QmpcParams& PK) {
   constexpr int RE = C::RE, KQ = C::KQ, SQ = C::SQ, NH = C::NH, NP = C::NP, KS = C::KS, MAXL = C::MAXL, LD = C::NP;
@@ -128,6 +399,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
   const QmpcParams& P = S.par;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (work item of the robot: `item` counts within this launch's chunk)
   const GlobalF64* const Hi = (const GlobalF64*)PK.wk_hinv + (size_t)item * (LD * LD);
   const GlobalF64* const xu = (const GlobalF64*)PK.wk_xu + (size_t)item * LD;
   const QmpcWorkHdr* const hd = PK.wk_hdr + item;
@@ -152,6 +424,16 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
   const int n = S.n, nst = S.nst, rid = S.rid;
   const int h = P.horizon;
   long long* dbg_clk = P.dbg_clk ? P.dbg_clk + (size_t)rid * 16 : nullptr;
+  if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
+  const bool blk = P.wk_block != 0;
+  if (blk) block_start<C>(tid, S, Hi, xu, n, nst, P.max_iter);
+  else if (tid == 0) {
+    S.bk.ne = 0;
+    S.bk.fail = 0;
+  }
+  __syncthreads();
+  const int bkev = S.bk.ne;  // records the block start left in the engine wave's pool (record e = event e)
+  if (dbg_clk && tid == 0) dbg_clk[13] = clock64();
   // event e: dealt round-robin over the engine wave (owner 0, LDS) and the holders (owners 1..NH, registers) while the
   // holders have room, then to the engine wave's LDS pool
   auto ev_owner = [](int e) __attribute__((always_inline)) { return e < C::NRR ? e % (NH + 1) : 0; };
@@ -163,7 +445,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
     const int kev = __builtin_amdgcn_readfirstlane(P.wk_kev < C::KEV ? P.wk_kev : C::KEV);
     auto uni = [](bool cnd) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(cnd) != 0ull; };
-    double xv[RE];
+    double xv[RE];  // (x_u, or the block start's minimiser on its working set)
 #pragma unroll
     for (int q = 0; q < RE; ++q) xv[q] = (lane + 64 * q < n) ? S.xl[lane + 64 * q] : 0.0;
     double fmx[SQ];
@@ -184,6 +466,48 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     int nle = 0;                        // events in the engine wave's own LDS pool
     unsigned long long dropme = 0ull;   // ... that are drop events
     bool retry = false;
+    if (bkev > 0) {
+      // ---- state left by the block start: x (already in xl), the working set and its multipliers by slot, membership
+      // masks, and the engine wave's share of the records (event e belongs to owner e mod (NH + 1)), compacted to the
+      // front of its pool once the holders have taken theirs (barrier)
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        wcid[k] = S.bk.wcid[lane + 64 * k];
+        lam[k] = S.bk.lam[lane + 64 * k];
+        const unsigned long long used = __ballot(wcid[k] >= 0);
+        if (used != 0ull) khw = 64 * k + 64 - __builtin_clzll(used);
+      }
+#pragma unroll
+      for (int s = 0; s < SQ; ++s) S.bk.bmask[lane + 64 * s] = 0u;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < KQ; ++k)
+        if (wcid[k] >= 0) atomicOr(&S.bk.bmask[wcid[k] / 5], 1u << (wcid[k] % 5));
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < SQ; ++s) amask[s] = S.bk.bmask[lane + 64 * s];
+      nev = bkev;
+      iters = bkev;  // (every forced addition / removal of the block start is a working-set change like an iteration's)
+      if (S.bk.fail != 0) retry = true;
+      lds_barrier();  // the holders have read their records
+      for (int li = 0; li * (NH + 1) < bkev; ++li) {
+        const int c = li * (NH + 1);
+        if (c != li) {
+          double tz[RE], tg[KQ];
+#pragma unroll
+          for (int q = 0; q < RE; ++q) tz[q] = S.epool[c][lane + 64 * q];
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) tg[k] = S.epool[c][NP + lane + 64 * k];
+#pragma unroll
+          for (int q = 0; q < RE; ++q) S.epool[li][lane + 64 * q] = tz[q];
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) S.epool[li][NP + lane + 64 * k] = tg[k];
+        }
+        if (S.bk.sign[c] < 0) dropme |= (1ull << li);
+        nle = li + 1;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
     double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
     auto rsqrt_full = [&](double d) __attribute__((always_inline)) {
@@ -265,6 +589,52 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       nev += 1;
     };
     __builtin_amdgcn_s_setprio(2);  // the serial part of the workgroup
+    // Remove working-set slot l: one drop event.  u = N*_l (variable lanes), sc = S^-1[:, l] (slot lanes) over ALL events (a
+    // round with the holders), gamma = S^-1[l][l].  With `repair` (after a block start: a row whose multiplier came out
+    // negative does not belong to the working set) the iterate also moves to the minimiser WITHOUT that row:
+    // x -= (lam_l / gamma) u, lam -= (lam_l / gamma) sc.  false: the projected inverse lost definiteness numerically.
+    auto drop_slot = [&](int l, bool repair) __attribute__((always_inline)) {
+      double u[RE], sc[KQ];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) u[q] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) sc[k] = 0.0;
+      round(CMD_DROPACC, l, u, sc, [&]() __attribute__((always_inline)) { own_events(std::false_type{}, l, u, sc); });
+      const double gamma = lane_elem<KQ>(sc, l);
+      if (uni(!(gamma > 0.0))) {
+        retry = true;
+        return false;
+      }
+      if (repair) {
+        const double coef = lane_elem<KQ>(lam, l) * fast_rcp(gamma);
+#pragma unroll
+        for (int q = 0; q < RE; ++q) {
+          xv[q] = __builtin_fma(-coef, u[q], xv[q]);
+          S.xl[lane + 64 * q] = xv[q];
+        }
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) lam[k] = __builtin_fma(-coef, sc[k], lam[k]);
+      }
+      const double sg = rsqrt_full(gamma);
+      const int de = lane_elem<KQ>(wcid, l);
+      double zv[RE], gv[KQ];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zv[q] = u[q] * sg;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
+      place_event(zv, gv, true, l);
+#pragma unroll
+      for (int k = 0; k < KQ; ++k)
+        if (lane + 64 * k == l) {
+          wcid[k] = -1;
+          lam[k] = 0.0;
+        }
+      const int dsl = de / 5, dty = de - 5 * dsl;
+#pragma unroll
+      for (int s2 = 0; s2 < SQ; ++s2)
+        if (lane + 64 * s2 == dsl) amask[s2] &= ~(1u << dty);
+      return true;
+    };
     double c1[RE], c2[RE];  // the two columns of H^-1 of the constraint being added (rows of the symmetric work item)
     // ---- the most violated constraint outside the working set (normalised by its row norm) becomes p, and the loads of
     // its two columns are issued; false: none is violated (optimal) or the iteration limit is reached.  The stance-slot
@@ -303,7 +673,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       psl = p_e / 5;
       pty = p_e - 5 * psl;
       con_coefs(p_e, mi, pj1, pj2, pa1, pa2);
-      p_rhs = (pty == 4) ? -(double)S.fmaxk[psl] : 0.0;
+      p_rhs = (pty == 4) ? -lane_elem<SQ>(fmx, psl) : 0.0;  // (f_max of the slot: from the slot lane's register, not LDS)
       lp = 0.0;
       // in flight across barrier (A) (which only orders LDS) and the accumulation over the events, and -- from the second
       // iteration on -- across the placement of the previous event; consumed right before (B)
@@ -314,7 +684,31 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       }
       return true;
     };
-    bool have_p = select_next();
+    // ---- after a block start: rows whose multiplier came out negative leave, most negative first, one drop event
+    // each -- what remains is a Goldfarb-Idnani state (x optimal on W, multipliers >= 0)
+    while (bkev > 0 && !retry) {  // (normally nothing left to do: the block start removes them itself while it has room)
+      double worst = 0.0;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        const double v = (wcid[k] >= 0 && lam[k] < 0.0) ? -lam[k] : 0.0;
+        worst = v > worst ? v : worst;
+      }
+      const double wmax = wave_max_pos_f64(worst);
+      if (!(wmax > 0.0)) break;
+      if (nev >= kev || iters >= max_iter) {
+        retry = true;
+        break;
+      }
+      int l = -1;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        const unsigned long long hit = __ballot(wcid[k] >= 0 && lam[k] < 0.0 && -lam[k] == wmax);
+        if (l < 0 && hit != 0ull) l = 64 * k + __ffsll((long long)hit) - 1;
+      }
+      if (!drop_slot(l, true)) break;
+      iters += 1;
+    }
+    bool have_p = !retry && select_next();
     while (have_p) {
       iters = __builtin_amdgcn_readfirstlane(iters);
       khw = __builtin_amdgcn_readfirstlane(khw);
@@ -339,8 +733,14 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       for (int k = 0; k < KQ; ++k) rw[k] = 0.0;
 #pragma unroll
       for (int q = 0; q < RE; ++q) z[q] = 0.0;
+      double d1 = 0.0, d2 = 0.0, xp1 = 0.0, xp2 = 0.0;
       round(CMD_ACC, 0, z, rw, [&]() __attribute__((always_inline)) {
         QMPC_ESTAMP(2);
+        // (operands of the step that do not depend on the holders: read while they work)
+        d1 = S.D[pj1];
+        d2 = S.D[pj2];
+        xp1 = S.xl[pj1];
+        xp2 = S.xl[pj2];
         own_events(std::true_type{}, 0, z, rw);
 #pragma unroll
         for (int q = 0; q < RE; ++q)
@@ -355,8 +755,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       });
       QMPC_ESTAMP(4);
       const double delta = __builtin_fma(pa2, lane_elem<RE>(z, pj2), pa1 * lane_elem<RE>(z, pj1));
-      const double cn = __builtin_fma(pa2 * pa2, S.D[pj2], pa1 * pa1 * S.D[pj1]);  // scale of c_p^T H^-1 c_p
-      const double sp = __builtin_fma(pa2, S.xl[pj2], pa1 * S.xl[pj1]) - p_rhs;
+      const double cn = __builtin_fma(pa2 * pa2, d2, pa1 * pa1 * d1);  // scale of c_p^T H^-1 c_p
+      const double sp = __builtin_fma(pa2, xp2, pa1 * xp1) - p_rhs;
       const bool dep = uni(!(delta > 1e-11 * cn));
       const double t2 = dep ? __builtin_inf() : -sp * fast_rcp(dep ? 1.0 : delta);
       double ratio[KQ], rmin = __builtin_inf();
@@ -372,7 +772,17 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       double t1 = __builtin_inf();
       int l = -1;
       if (khw > 0 && uni(rmin < __builtin_inf())) {
-        t1 = wave_min_pos_f64(rmin);
+        // the smallest ratio: ONE 32-bit wave reduction on the ratios rounded to float (non-negative: bit pattern order ==
+        // value order); the usual case -- one lane at the minimum -- is settled by a ballot, ties in float by the exact
+        // two-pass reduction (the answer is the exact minimum either way)
+        const unsigned rf = __float_as_uint((float)rmin);
+        const unsigned mf = wave_min_u32(rf);
+        const unsigned long long cand = __ballot(rf == mf);
+        if ((cand & (cand - 1ull)) == 0ull) {
+          t1 = readlane_f64(rmin, __ffsll((long long)cand) - 1);
+        } else {
+          t1 = wave_min_pos_f64(rmin);
+        }
 #pragma unroll
         for (int k = 0; k < KQ; ++k) {
           const unsigned long long hit = __ballot(ratio[k] == t1);
@@ -435,37 +845,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
         have_p = select_next();
         place_event(zv, gv, false, -1);
       } else {
-        // ---- partial step: the multiplier of slot l reached zero -> drop it (a drop event).  u = N*_l (variable
-        // lanes), sc = S^-1[:, l] (slot lanes) over ALL events: a second round.  p stays (its columns are still in c1, c2)
-        double u[RE], sc[KQ];
-#pragma unroll
-        for (int q = 0; q < RE; ++q) u[q] = 0.0;
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) sc[k] = 0.0;
-        round(CMD_DROPACC, l, u, sc, [&]() __attribute__((always_inline)) { own_events(std::false_type{}, l, u, sc); });
-        const double gamma = lane_elem<KQ>(sc, l);
-        if (uni(!(gamma > 0.0))) {
-          retry = true;  // numerically lost S^-1[l][l] > 0
-          break;
-        }
-        const double sg = rsqrt_full(gamma);
-        const int de = lane_elem<KQ>(wcid, l);
-        double zv[RE], gv[KQ];
-#pragma unroll
-        for (int q = 0; q < RE; ++q) zv[q] = u[q] * sg;
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
-        place_event(zv, gv, true, l);
-#pragma unroll
-        for (int k = 0; k < KQ; ++k)
-          if (lane + 64 * k == l) {
-            wcid[k] = -1;
-            lam[k] = 0.0;
-          }
-        const int dsl = de / 5, dty = de - 5 * dsl;
-#pragma unroll
-        for (int s2 = 0; s2 < SQ; ++s2)
-          if (lane + 64 * s2 == dsl) amask[s2] &= ~(1u << dty);
+        // ---- partial step: the multiplier of slot l reached zero -> drop it.  p stays (its columns are still in c1, c2)
+        if (!drop_slot(l, false)) break;
       }
       __builtin_amdgcn_wave_barrier();
       if (dbg_clk && lane == 0 && iters == QMPC_EDBG_ITER + 1) dbg_clk[7] = clock64();
@@ -539,6 +920,20 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     }
     int nloc = 0, hround = 0;
     unsigned long long dropm = 0ull;  // local events that are drop events
+    if (bkev > 0) {
+      // the block start's records: event e belongs to owner e mod (NH + 1), registers [e / (NH + 1)]
+      nloc = (bkev > wv) ? (bkev - wv + NH) / (NH + 1) : 0;
+      Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
+        constexpr int li = decltype(lic)::value;
+        const int c = li * (NH + 1) + wv;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zt[li][q] = S.epool[c][lane + 64 * q];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) gt[li][k] = S.epool[c][NP + lane + 64 * k];
+        if (S.bk.sign[c] < 0) dropm |= (1ull << li);
+      });
+      lds_barrier();  // (the engine wave compacts its own records after this)
+    }
     while (true) {
       lds_barrier();  // (A)
       const bool hst = dbg_clk && wv == 1 && lane == 0 && hround == QMPC_EDBG_ITER;  // (rounds ~ iterations while nothing is dropped)
@@ -665,7 +1060,7 @@ __global__ __launch_bounds__(64 * NW, 2) void qmpc_engine_kernel(const QmpcParam
     int tid1 = (int)threadIdx.x;
     asm volatile("" : "+v"(tid1));
     __builtin_assume(tid1 >= 0 && tid1 < 64 * NW);
-    engine_item<C, false>(idx, tid1, S, P);
+    engine_item<C, false>(P.wk_base + idx, tid1, S, P);
     if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.wk_qhead, 1);
     __syncthreads();
     idx = S.qnext;
@@ -699,10 +1094,10 @@ struct EngineEntry {
 };
 // engine of the 128-row class: 2 row blocks, 64 working slots, 64 stance slots; 3 holders x 26 events (6 VGPRs per event;
 // 256 VGPRs per lane at two waves per SIMD, ~100 of them for everything else)
-typedef EngineEntry<2, 1, 1, 4, 24, 40> Engine2;
+typedef EngineEntry<2, 1, 1, 4, 23, 42> Engine2;
 // engine of the 192-row class: 3 row blocks, 128 working slots (all four feet down at horizon 14 / 16 ends with 70-90 rows at
 // a bound when braking): 10 VGPRs per event, 7 holders x 15 + 24 in LDS
-typedef EngineEntry<3, 2, 1, 8, 14, 24> Engine3;
+typedef EngineEntry<3, 2, 1, 8, 13, 48> Engine3;
 }  // namespace
 
 extern "C" hipError_t qmpc_engine_prepare(void) {

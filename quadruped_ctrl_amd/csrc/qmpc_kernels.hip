@@ -561,7 +561,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   }
   const double alpha = (double)g_alpha;
   if constexpr (PHA) {
-    if (tid == 0) S.evslot = atomicAdd(P.wk_count, 1);  // this robot's work item (read after barrier 2)
+    if (tid == 0) S.evslot = P.wk_base + atomicAdd(P.wk_count, 1);  // this robot's work item (read after barrier 2)
   }
   // ------------------------------------------------------------ stage 1
   // E_00 = B0^T W B0, E_11 = B1^T W B1 in closed form, and the weighted sums
@@ -2556,13 +2556,15 @@ template <int RB, bool CMD, bool LISTED = false>
 __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES_A) void qmpc_sweep_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  // (a launch covers one CHUNK of the class: robots / list entries rid0 .. ; the chunks of a call run on separate streams)
   if constexpr (!LISTED) {
     if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
-    solve_one<RB, true, CMD, false, false, true>((int)blockIdx.x, (int)threadIdx.x, S, P);
+    solve_one<RB, true, CMD, false, false, true>(P.rid0 + (int)blockIdx.x, (int)threadIdx.x, S, P);
   } else {
-    const int nlist = *P.count;
-    if ((int)blockIdx.x >= nlist) return;  // uniform
-    for (int idx = (int)blockIdx.x;;) {
+    int nlist = *P.count;
+    nlist = nlist < P.list_hi ? nlist : P.list_hi;
+    if (P.rid0 + (int)blockIdx.x >= nlist) return;  // uniform
+    for (int idx = P.rid0 + (int)blockIdx.x;;) {
       const int rid = P.list[idx];
       int tid1 = (int)threadIdx.x;
       asm volatile("" : "+v"(tid1));
@@ -2573,7 +2575,7 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES_A) void qmpc_sweep_
       const QmpcParams& PK = *(const QmpcParams*)pk;
       solve_one<RB, true, CMD, false, false, true>(rid, tid1, S, PK);
       __syncthreads();
-      if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+      if (threadIdx.x == 0) S.qnext = P.rid0 + (int)gridDim.x + atomicAdd(P.qhead, 1);
       __syncthreads();
       idx = S.qnext;
       if (idx >= nlist) break;  // uniform

@@ -862,6 +862,23 @@ def test_decoupled_path_matches_one_kernel_path_and_qpoases(mk, name, mpc_factor
         assert np.array_equal(again["soln"], res["soln"]) and np.array_equal(again["status"], res["status"])
 
 
+def test_decoupled_engine_block_start_same_minimiser(mpc_factory):
+    """The engine's experimental block start (forced additions by all threads, removal of the rows with negative
+    multipliers, then the normal iteration: qmpc_set_block_start) reaches the same unique minimiser as the plain
+    iteration, on braking robots with 30 - 60 working-set changes and on calm ones with a handful."""
+    for b in (W.make_standing(200, 10), W.make_standing(130, 14), W.make_standing(96, 10, calm=True)):
+        m = mpc_factory(b)
+        base = m.solve(b, full=True)
+        m.set_block_start(True)
+        blk = m.solve(b, full=True)
+        m.set_block_start(False)
+        assert ((base["status"] & 47) == 0).all() and ((blk["status"] & 47) == 0).all()
+        scale = np.abs(base["soln"]).max(1).clip(1.0)
+        d = (np.abs(blk["soln"] - base["soln"]).max(1) / scale).max()
+        print("block start vs plain iteration:", d, "changes", float(blk["iters"].mean()), "vs iterations", float(base["iters"].mean()))
+        assert d < 1e-10
+
+
 def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
     """The engine kernel keeps the rank-1 events in registers / LDS: a robot that needs more of them than fit is handed
     back through a list and solved from scratch by the one-kernel path in the same call (status bit 16), same answer.

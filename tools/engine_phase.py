@@ -36,3 +36,6 @@ okh = ok & (c[:, 11] > c[:, 8]) & (c[:, 8] > 0)
 mh = lambda a: float(np.median(a[okh]))
 print(f"   HOLDER 1: request read + ingest {mh(c[:,9]-c[:,8]):.0f} | accumulate {mh(c[:,10]-c[:,9]):.0f} | partial sums out {mh(c[:,11]-c[:,10]):.0f}"
       f" | (A)->(B) {mh(c[:,11]-c[:,8]):.0f}")
+okb = (c[:, 13] > c[:, 12]) & (c[:, 12] > 0) & (c[:, 6] > c[:, 13])
+print(f"   block start: median {np.median((c[:,13]-c[:,12])[okb]):.0f} cycles (max {np.max((c[:,13]-c[:,12])[okb]):.0f}); "
+      f"rest of the item (iteration + output) median {np.median((c[:,6]-c[:,13])[okb]):.0f} (max {np.max((c[:,6]-c[:,13])[okb]):.0f}); iters mean {it.mean():.1f} max {it.max()}")
