@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index")
-    ap.add_argument("--workload", choices=["config", "standing", "trot"], default="config",
+    ap.add_argument("--workload", choices=["config", "standing", "trot", "long-trot", "long-bound"], default="config",
                     help="'standing' = all four feet down for the whole horizon (the robot's default posture, the "
                          "reference's Standing gait, ConvexMPCLocomotion.cpp:35: n_r = 12 h); 'trot' = trot at --horizon")
     ap.add_argument("--horizon", type=int, default=10, help="for --workload standing / trot (reference: 10, 14, 16)")
@@ -206,15 +206,19 @@ def main():
         wkey = f"config{args.config}"
     else:
         per_gpu = args.batch or 1024
-        mk = workloads.make_standing if args.workload == "standing" else workloads.make_trot
-        full = mk(per_gpu * world, args.horizon)
+        if args.workload in ("long-trot", "long-bound"):
+            # horizons beyond the reference's own gaits, up to K_MAX_GAIT_SEGMENTS = 36 (the 192-row class)
+            full = workloads.make_long_horizon(per_gpu * world, args.horizon, "trot" if args.workload == "long-trot" else "bound")
+        else:
+            mk = workloads.make_standing if args.workload == "standing" else workloads.make_trot
+            full = mk(per_gpu * world, args.horizon)
         spec = {"kind": args.workload, "horizon": args.horizon, "batch": per_gpu}
-        wname = f"{args.workload} (all four feet in stance)" if args.workload == "standing" else "trot"
+        wname = f"{args.workload} (all four feet in stance)" if args.workload == "standing" else args.workload
         wkey = f"{args.workload}_h{args.horizon}"
     b = workloads.shard(full, rank, world)
     h = b["horizon"]
 
-    mpc = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=16)
+    mpc = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=max(16, h))
     mpc.setup(b["dt"], h, b["mu"], b["f_max"])
     max_stance = int((b["gait"] != 0).sum(1).max())
     min_stance = int((b["gait"] != 0).sum(1).min())
@@ -303,7 +307,7 @@ def main():
     if world == 1 and not args.caller_side and not args.no_pipelined:
         streams = [torch.cuda.Stream(dev) for _ in range(2)]
         ctx = [(mpc, inp, out)]
-        mpc2 = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=16)
+        mpc2 = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=max(16, h))
         mpc2.setup(b["dt"], h, b["mu"], b["f_max"])
         if not args.no_hint:
             mpc2.set_max_stance(max_stance)

@@ -48,8 +48,13 @@
 extern "C" {
 #endif
 
-#define QMPC_MAX_HORIZON 16 /* largest horizon the reference uses
-                               (src/MPC_Ctrl/ConvexMPCLocomotion.cpp:196,204) */
+#define QMPC_MAX_HORIZON 36 /* K_MAX_GAIT_SEGMENTS (src/MPC_Ctrl/convexMPC_interface.h:3).  The reference's own gaits
+                               use 10 .. 16 segments (ConvexMPCLocomotion.cpp:25,196,204): every size class takes those.
+                               Longer horizons (17 .. 36) are assembled by the 192-row class only, i.e. for robots with
+                               at most 64 stance foot-steps in the horizon (n_r = 3 x stance foot-steps <= 192: trot up
+                               to 32 segments, gaits with a duty factor <= 0.44 up to 36); a robot with more is reported
+                               with QMPC_ST_WS_FULL (zero forces), like any robot beyond a size hint */
+#define QMPC_LONG_HORIZON 16 /* horizons above this take the long-horizon route described above */
 
 /* return codes */
 #define QMPC_OK 0

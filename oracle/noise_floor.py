@@ -41,7 +41,9 @@ def variants(b, i):
         _, Hr, gr, _, _, _ = O.reduce(H, g, A, lb, ub)
         q = np.zeros(n)
         if gr.size:
-            x, _, _, rc, irc = O.qpoases(Hr, gr, Ar, lr, ur)
+            # (no cap of 100 working-set recalculations here: the floor is a property of the assembly, and long
+            #  horizons with many rows at a bound need more of them)
+            x, _, _, rc, irc = O.qpoases(Hr, gr, Ar, lr, ur, nwsr=5000)
             assert rc == 0 and irc == 0
             q[~ve] = x
         return q

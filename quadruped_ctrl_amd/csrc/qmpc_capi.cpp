@@ -614,6 +614,14 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   // ... and with a lower bound the classes that are too small for every robot are skipped
   int k0 = 0;
   while (k0 + 1 < nclass_eff && 3 * (full_problem ? 4 * h : c->min_stance) > rows[k0]) ++k0;
+  if (h > QMPC_LONG_HORIZON) {
+    // long horizons (up to K_MAX_GAIT_SEGMENTS = 36): the 192-row class alone has the threads (12 h tracking-error
+    // entries, one per thread) and the LDS (h x h coefficient tables) to assemble them -- it takes every robot; one with
+    // more than 64 stance foot-steps is reported (QMPC_ST_WS_FULL)
+    if (full_problem) return QMPC_ERR_ARG;  // (use_jcqp = 1 keeps all 12 h variables: beyond 192 rows)
+    k0 = 3;
+    nclass_eff = 4;
+  }
   for (int k = k0; k < nclass_eff; ++k) {
     P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
     P.count = k > k0 ? cnt + (k - 1) : nullptr;

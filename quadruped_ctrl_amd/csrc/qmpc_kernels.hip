@@ -168,6 +168,10 @@ struct Cfg {
 #define QMPC_HELP_MIN_TRIPS 3
 #endif
   static constexpr int HELP_MIN_TRIPS = QMPC_HELP_MIN_TRIPS;
+  // horizons this class assembles: the reference's gaits use 10 .. 16 segments; its interface takes up to
+  // K_MAX_GAIT_SEGMENTS = 36 (convexMPC_interface.h:3).  The long ones (h > 16) are assembled by the 192-row class only:
+  // its 768 threads cover the 12 h <= 432 tracking-error entries one per thread, and it alone has the LDS for h x h tables
+  static constexpr int HMAX = (RB == 3) ? 36 : 16;
   static constexpr int MIN_WAVES = (RB == 1 || RB == 4) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
   // ... of the producer half of the decoupled path (qmpc_sweep_kernel): without the packed inverse its LDS is the
   // assembly / sweep storage only, so the 128-row class fits two workgroups per CU if it stays within 128 VGPRs
@@ -184,7 +188,7 @@ struct Smem {
   QmpcParams par;  // kernel parameters parked in LDS (keeps ~45 uniforms out of SGPRs)
   double fmaxk[64];
   unsigned char sidx[64];
-  unsigned char kslot[64];  // foot-step k -> stance slot (0xff = swing): inverse of sidx, for the warm start
+  unsigned char kslot[4 * C::HMAX];  // foot-step k -> stance slot (0xff = swing): inverse of sidx, for the warm start
   int nst, status;
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   int evslot;  // class 3: this workgroup's slice of the global event pool
@@ -203,11 +207,11 @@ struct Smem {
         double Mb[4][9];  // M_b = I_world^-1 [r_b]x                 (B0 rows 6..8)
         double Nb[4][9];  // N_b = R_yaw^T M_b                       (B1 rows 0..2)
         double W[12];
-        double ct0[256], ct4[256];            // C_00 (tau), C_11 (sigma)
-        double ct1[256], ct5[256], ct8[256];  // C_01, C_12, C_22 (x_drag != 0 only)
+        double ct0[C::HMAX * C::HMAX], ct4[C::HMAX * C::HMAX];  // C_00 (tau), C_11 (sigma)
+        double ct1[C::HMAX * C::HMAX], ct5[C::HMAX * C::HMAX], ct8[C::HMAX * C::HMAX];  // C_01, C_12, C_22 (x_drag != 0 only)
         double E00[144], E11[144];
-        double e[16 * 12];
-        double s[3][16 * 12];
+        double e[C::HMAX * 12];
+        double s[3][C::HMAX * 12];
       } a;
       struct Swp {  // sweep + unconstrained minimiser (stages 2-4)
         alignas(16) double colbuf[2][2][C::NP + 2];  // [parity][column of the pair][row]
@@ -262,7 +266,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   const int i = tid % NP;  // matrix row owned by this thread
   const int c = tid / NP;  // column group (0..3): columns c*CW .. c*CW+CW-1
   const int h = PK.horizon;
-  const int nfs = 4 * h;   // foot-steps in the horizon (<= 64)
+  const int nfs = 4 * h;   // foot-steps in the horizon (<= 64; <= 144 in the 192-row class, horizons up to 36)
+  constexpr int HMAX = C::HMAX;
+  constexpr int NFG = (4 * HMAX + 63) / 64;  // 64-foot-step groups of the contact table
   long long* dbg_clk = PK.dbg_clk ? PK.dbg_clk + (size_t)rid * 16 : nullptr;
   QMPC_TICK(0);
 #if QMPC_SWEEP_PRIO && QMPC_START_PRIO
@@ -310,14 +316,23 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                       PK.c_yaw_des_true[rid], PK.c_wpd[(size_t)rid * 2 + 0], PK.c_wpd[(size_t)rid * 2 + 1], c_p0, c_p1,
                       PK.c_body_height, PK.c_vel_des[(size_t)rid * 3 + 2], vw0, vw1, (float)PK.dt);
   }
-  unsigned char g_gait = 0;
-  if (tid < nfs) {
+  // contact table: wave 0 takes foot-step lane + 64 g of every 64-foot-step group g (one group up to horizon 16)
+  auto gait_at = [&](int fs) __attribute__((always_inline)) {
     if (cmdm) {
-      const int leg = tid & 3;
-      g_gait = (unsigned char)qmpc_cmd_gait_bit(tid >> 2, PK.c_gait_iteration[rid], PK.c_gait_offsets[(size_t)rid * 4 + leg],
-                                                PK.c_gait_durations[(size_t)rid * 4 + leg], h);
-    } else {
-      g_gait = PK.gait[(size_t)rid * nfs + tid];
+      const int leg = fs & 3;
+      return (unsigned char)qmpc_cmd_gait_bit(fs >> 2, PK.c_gait_iteration[rid], PK.c_gait_offsets[(size_t)rid * 4 + leg],
+                                              PK.c_gait_durations[(size_t)rid * 4 + leg], h);
+    }
+    return (unsigned char)PK.gait[(size_t)rid * nfs + fs];
+  };
+  unsigned char g_gait = 0;
+  unsigned char g_gaitx[NFG > 1 ? NFG - 1 : 1] = {};
+  if (tid < nfs) g_gait = gait_at(tid);
+  if constexpr (NFG > 1) {
+    if (tid < WAVE) {
+#pragma unroll
+      for (int g = 1; g < NFG; ++g)
+        if (tid + 64 * g < nfs) g_gaitx[g - 1] = gait_at(tid + 64 * g);
     }
   }
   float g_r0 = 0.f, g_r1 = 0.f, g_r2 = 0.f;
@@ -364,7 +379,19 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   //  for by barrier 2)
   float g_alpha = cmdm ? 4e-5f : PK.alpha[(size_t)rid * PK.alpha_stride];  // ConvexMPCLocomotion.cpp:604
   double g_ct0 = 0.0, g_ct4 = 0.0, g_ct1 = 0.0, g_ct5 = 0.0, g_ct8 = 0.0;
-  if (tid < hh) {  // h*h <= 256 == NT for RB = 1; larger classes loop below
+  // (h * h <= 256 == NT in the 64-row class; the 192-row class -- 768 threads, h * h up to 1296 -- takes a second entry)
+  constexpr bool TAB2 = HMAX * HMAX > NT;
+  double g2_ct0 = 0.0, g2_ct4 = 0.0, g2_ct1 = 0.0, g2_ct5 = 0.0, g2_ct8 = 0.0;
+  if constexpr (TAB2) {
+    if (tid + NT < hh) {
+      g2_ct0 = PK.ctab[tid + NT];
+      g2_ct4 = PK.ctab[4 * hh + tid + NT];
+      g2_ct1 = PK.ctab[1 * hh + tid + NT];
+      g2_ct5 = PK.ctab[5 * hh + tid + NT];
+      g2_ct8 = PK.ctab[8 * hh + tid + NT];
+    }
+  }
+  if (tid < hh) {
     // the x_drag tables are fetched unconditionally: making them wait for the x_drag
     // value would put a second memory round trip in front of them
     g_ct0 = PK.ctab[tid];
@@ -384,6 +411,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
                  "+v"(g_w[2]), "+v"(g_v[0]), "+v"(g_v[1]), "+v"(g_v[2]), "+v"(g_p), "+v"(g_traj), "+v"(g_wt),
                  "+v"(g_w12), "+v"(g_ct0), "+v"(g_ct4), "+v"(g_ct1), "+v"(g_ct5), "+v"(g_ct8));
     g_gait = (unsigned char)gg;
+    if constexpr (TAB2) asm volatile("" : "+v"(g2_ct0), "+v"(g2_ct4), "+v"(g2_ct1), "+v"(g2_ct5), "+v"(g2_ct8));
   }
   if (tid < (int)(sizeof(QmpcParams) / 4)) reinterpret_cast<uint32_t*>(&S.par)[tid] = g_par;
   const double x_drag = (double)g_xdrag;
@@ -394,20 +422,26 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     asm volatile("" ::"v"(sink));
     dbg_clk[11] = clock64();
   }
-  // ---- stance list
+  // ---- stance list (wave 0; group after group when the horizon has more than 64 foot-steps)
   if (tid < WAVE) {
-    const float fm = (float)g_gait * (float)PK.f_max;  // :361
-    // (use_jcqp == 1 hands JCQP the FULL problem, swing foot-steps included with u = 0: SolverMPC.cpp:400-407)
-    const bool st = (ADMM && PK.admm_mode == 1) ? (tid < nfs) : !(fm < 0.01f && fm > -.01f);  // :64-67
-    const unsigned long long mask = __ballot(st);
-    const int pos = __popcll(mask & ((1ull << tid) - 1ull));
-    if (st) {
-      S.sidx[pos] = (unsigned char)tid;
-      S.fmaxk[pos] = (double)fm;
+    int base = 0;
+#pragma unroll
+    for (int g = 0; g < NFG; ++g) {
+      const int fs = tid + 64 * g;
+      const float fm = (float)(g == 0 ? g_gait : g_gaitx[g > 0 ? g - 1 : 0]) * (float)PK.f_max;  // :361
+      // (use_jcqp == 1 hands JCQP the FULL problem, swing foot-steps included with u = 0: SolverMPC.cpp:400-407)
+      const bool st = fs < nfs && ((ADMM && PK.admm_mode == 1) ? true : !(fm < 0.01f && fm > -.01f));  // :64-67
+      const unsigned long long mask = __ballot(st);
+      const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
+      if (st && pos < 64) {  // (more than 64 stance foot-steps: n_r > 192, no class takes the robot -- reported below)
+        S.sidx[pos] = (unsigned char)fs;
+        S.fmaxk[pos] = (double)fm;
+      }
+      if (fs < 4 * HMAX) S.kslot[fs] = (st && pos < 64) ? (unsigned char)pos : (unsigned char)0xff;
+      base += __popcll(mask);
     }
-    S.kslot[tid] = st ? (unsigned char)pos : (unsigned char)0xff;
     if (tid == 0) {
-      S.nst = __popcll(mask);
+      S.nst = base;
       S.status = 0;
     }
   }
@@ -502,6 +536,17 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         Aa.ct8[tid] = g_ct8;
       }
     }
+    if constexpr (TAB2) {
+      if (tid + NT < hh) {
+        Aa.ct0[tid + NT] = g2_ct0;
+        Aa.ct4[tid + NT] = g2_ct4;
+        if (drag) {
+          Aa.ct1[tid + NT] = g2_ct1;
+          Aa.ct5[tid + NT] = g2_ct5;
+          Aa.ct8[tid + NT] = g2_ct8;
+        }
+      }
+    }
   }
   if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
   __syncthreads();  // ---- barrier 1
@@ -592,13 +637,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   // instead of O(h^2) LDS-bound dot products on every thread.
   if (tid >= 192 && tid < 204) {
     const int row = tid - 192;
-    double ek[16];
+    double ek[HMAX];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) ek[k] = Aa.e[(k < h ? k : 0) * 12 + row];
+    for (int k = 0; k < HMAX; ++k) ek[k] = Aa.e[(k < h ? k : 0) * 12 + row];
     const double dt1 = P.dt, dt2 = dt1 * dt1, dt3 = dt2 * dt1;
     double S0 = 0.0, S1 = 0.0, S2 = 0.0;
 #pragma unroll
-    for (int st = 15; st >= 0; --st) {
+    for (int st = HMAX - 1; st >= 0; --st) {
       if (st < h) {
         S2 = S2 + 2.0 * S1 + S0;
         S1 = S1 + S0;

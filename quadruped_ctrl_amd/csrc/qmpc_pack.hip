@@ -47,10 +47,10 @@ __global__ __launch_bounds__(256) void qmpc_pack_kernel(const qmpc_command c, co
     const int k = idx / 12, j = idx - 12 * k;
     rec.traj[(size_t)b * 12 * h + idx] = qmpc_cmd_traj_value(g, k, j);
   }
-  if (lane < 4 * h) {
-    const int leg = lane & 3;
-    rec.gait[(size_t)b * 4 * h + lane] = (uint8_t)qmpc_cmd_gait_bit(lane >> 2, c.gait_iteration[b], c.gait_offsets[(size_t)b * 4 + leg],
-                                                                     c.gait_durations[(size_t)b * 4 + leg], h);
+  for (int fs = lane; fs < 4 * h; fs += 64) {  // (more than 64 foot-steps beyond horizon 16)
+    const int leg = fs & 3;
+    rec.gait[(size_t)b * 4 * h + fs] = (uint8_t)qmpc_cmd_gait_bit(fs >> 2, c.gait_iteration[b], c.gait_offsets[(size_t)b * 4 + leg],
+                                                                   c.gait_durations[(size_t)b * 4 + leg], h);
   }
   if (lane < 12) {
     const int leg = lane & 3, ax = lane >> 2;  // axis-major (:611-613)

@@ -37,7 +37,7 @@ def mpc_factory():
     made = []
 
     def make(b, max_batch=None):
-        m = BatchedConvexMPC(0, max_batch=max_batch or max(int(b["batch"]), 1), max_horizon=16)
+        m = BatchedConvexMPC(0, max_batch=max_batch or max(int(b["batch"]), 1), max_horizon=max(16, int(b["horizon"])))
         m.setup(b["dt"], b["horizon"], b["mu"], b["f_max"])
         made.append(m)
         return m

@@ -430,6 +430,50 @@ def test_reference_shim_real_horizons_double_entry_drag_and_horizon_changes():
                 assert lib.get_solution(12 * h) == 0.0                    # past the horizon: 0, no overrun
 
 
+@pytest.mark.parametrize("h,gait,B", [(24, "trot", 96), (32, "trot", 64), (36, "bound", 96), (20, "bound", 64)])
+def test_long_horizons_vs_oracle(h, gait, B, mpc_factory):
+    """Horizons beyond the reference's own gaits, up to K_MAX_GAIT_SEGMENTS = 36 (convexMPC_interface.h:3), which the
+    reference's interface accepts and round 2 refused: assembled and swept by the 192-row class (n_r <= 192), active set
+    by the decoupled engine.  (a) assembled H_red, g_red against the fp64 Kronecker model (same float transcendentals)
+    <= 1e-10; (b) the solution against the reference's qpOASES on the GPU's own QP <= 1e-8; (c) end to end against the
+    oracle pipeline (float assembly restatement + the reference's qpOASES) within the reference's own float-order spread."""
+    b = W.make_long_horizon(B, h, gait)
+    nst = (b["gait"] != 0).sum(1)
+    assert 3 * nst.max() <= 192
+    m = mpc_factory(b)
+    res, idx, worst, nact = _solver_parity_on_own_qp(m, b, lambda r: np.argsort(r["iters"])[-4:], nwsr=5000)
+    assert ((res["status"] & 47) == 0).all()
+    ref, nwsr, rc = O.solve_batch(b)
+    # The reference caps qpOASES at nWSR = 100 working-set recalculations and ignores init()'s return value
+    # (SolverMPC.cpp:435, :539-541): with 56 - 64 stance foot-steps and flight phases many robots need more, and the
+    # reference then returns a NON-optimal point (negative f_z among them).  Those robots are no reference: for them the
+    # check is (b), against the same qpOASES with the cap lifted
+    ok = np.nonzero((rc == 0) & (nwsr < 100))[0]
+    print(f"   reference hit its nWSR = 100 cap on {B - len(ok)} of {B} robots")
+    assert len(ok) >= 3
+    err, bd = rel_f0(res["grf"][ok], ref[ok]), bound_for(b, ok)
+    report(f"long horizon h={h} {gait} (n_r {3 * nst.min()}..{3 * nst.max()})", err, bd)
+    print("   solver vs qpOASES on own QP", worst, "iters", float(res["iters"].mean()), "nWSR", float(nwsr.mean()))
+    assert (err < bd).all()
+    assert abs(float(res["iters"][ok].mean()) - float(nwsr[ok].mean())) < 1.5
+    # swing feet are exactly zero, every stance foot-step of the horizon is a variable block
+    sw = np.repeat(b["gait"] == 0, 3, axis=1)
+    assert np.all(res["soln"][sw] == 0.0) and res["soln"].shape[1] == 12 * h
+
+
+def test_long_horizon_beyond_192_rows_is_reported(mpc_factory):
+    """A long-horizon robot with more than 64 stance foot-steps (trot at horizon 36: n_r = 216) is beyond the 192-row
+    class: reported with QMPC_ST_WS_FULL and zero forces, its neighbours that fit are solved."""
+    b = W.make_long_horizon(8, 36, "trot")
+    small = W.make_long_horizon(8, 36, "bound")
+    for k in ("gait",):
+        b[k][4:] = small[k][4:]
+    m = mpc_factory(b)
+    res = m.solve(b, full=True)
+    assert ((res["status"][:4] & 8) != 0).all() and np.all(res["grf"][:4] == 0.0) and np.all(res["soln"][:4] == 0.0)
+    assert ((res["status"][4:] & 47) == 0).all() and np.abs(res["grf"][4:]).max() > 1.0
+
+
 def test_jcqp_alternate_vs_model(mpc_factory):
     """use_jcqp = 1 / 2 reproduces the reference's JCQP ADMM (QpProblem.cpp:178-269) --
     same iterate after the same number of iterations as the numpy restatement (oracle/jcqp_model.py), for
@@ -1304,8 +1348,9 @@ def _sparse_exact(b, i):
 
 
 @pytest.mark.parametrize("mk", [lambda: W.make_config(2, batch=10), lambda: W.make_config(4, batch=10),
-                                lambda: W.make_trot(6, 16), lambda: W.make_standing(3, 14, calm=True)],
-                         ids=["mixed_h10", "stairs_random_h10", "trot_h16", "standing_h14"])
+                                lambda: W.make_trot(6, 16), lambda: W.make_standing(3, 14, calm=True),
+                                lambda: W.make_long_horizon(4, 24, "trot"), lambda: W.make_long_horizon(4, 36, "bound")],
+                         ids=["mixed_h10", "stairs_random_h10", "trot_h16", "standing_h14", "trot_h24", "bound_h36"])
 def test_sparse_formulation_model(mk, mpc_factory):
     """QMPC_MODEL_SPARSE returns the exact minimiser of the reference's SPARSE formulation
     (SparseCMPC.cpp:31-73 with SparseCMPC_Math.cpp's discretisation), with SparseCMPC's own parameters
