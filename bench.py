@@ -394,7 +394,7 @@ def main():
                 ent = json.load(open(pmc)).get(wkey)
                 if ent and ent.get("batch") == per_gpu:
                     if ent.get("kernel_source_sha") == kernel_source_hash():
-                        traffic = ent.get("hbm_bytes_per_launch")
+                        traffic = ent.get("hbm_bytes_per_launch")       # (per step: summed over the step's kernels)
                         executed = ent.get("fp64_flops_per_launch")
                         pmc_extra = {"lds_bank_conflict_rate": ent.get("lds_bank_conflict_rate"),
                                      "wave_cycle_shares": ent.get("wave_cycle_shares"),
@@ -410,7 +410,12 @@ def main():
         kclass = 1 if nr_max <= 64 else (4 if nr_max <= 96 else (2 if nr_max <= 128 else 3))
         # template arguments: <size class, command mode, warm start, list-consuming>; the dominant kernel of a uniform
         # workload is the first of its chain (not list-consuming) -- the name rocprofv3 --kernel-trace --stats reports
-        kname = f"qmpc_solve_kernel<{kclass}, {'true' if args.caller_side == 'fused' else 'false'}, false, false>"
+        cm = 'true' if args.caller_side == 'fused' else 'false'
+        kname = f"qmpc_solve_kernel<{kclass}, {cm}, false, false>"
+        if kclass in (2, 3) and os.environ.get("QMPC_NO_SPLIT", "0") != "1":
+            # decoupled path: the step is the sweep kernel, the engine kernel and the (normally empty) hand-back launch
+            kname = (f"qmpc_sweep_kernel<{kclass}, {cm}, false> + qmpc_engine_kernel<{kclass}, ...> "
+                     f"(+ qmpc_solve_kernel<{kclass}, {cm}, false, true> on handed-back robots)")
         t_s = step_ms_ev * 1e-3
         res = {
             "metric": "convex-MPC QP solves/sec (horizon=%d, 4-leg)" % h,

@@ -186,9 +186,13 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
  * by qmpc_reserve), and the active set is run by a second kernel, one robot per small workgroup with the rank-1
  * events of the method in the register file of helper waves -- instead of one workgroup pinning a whole CU for the
  * whole solve.  Same unique minimiser; a robot that outgrows the engine's registers is re-solved by the
- * one-kernel path.  off: the one-kernel path for every class (QMPC_NO_SPLIT=1 in the environment selects that
- * at qmpc_create).  The JCQP alternate and warm-started solves always take the one-kernel path. */
-int qmpc_set_split(qmpc_handle h, int on);
+ * one-kernel path.  mode 1 (default): used by handles created for at least 384 robots (128-row class) / 128 robots
+ * (192-row class) -- smaller batches are latency-bound and the one-kernel path has one launch less on the critical
+ * path; it is the handle's max_batch that decides, never the size of a call, so that a robot's result does not depend
+ * on the batch it is solved in (the two paths agree to ~1e-14 relative, not bit for bit); mode 2:
+ * always; mode 0: the one-kernel path for every class (QMPC_NO_SPLIT=1 in the environment selects that at
+ * qmpc_create).  The JCQP alternate and warm-started solves always take the one-kernel path. */
+int qmpc_set_split(qmpc_handle h, int mode);
 /* Block start of the decoupled path's engine -- EXPERIMENTAL, default off.  The rows of the friction pyramids / force
  * limits that are violated at the unconstrained minimiser are, almost without exception, active at the solution; with
  * on != 0 the engine adds such candidate sets (one row per stance foot-step and round, up to four rounds) as forced
@@ -217,8 +221,9 @@ int qmpc_reserve(qmpc_handle h);
  * continues with the normal dual active-set iteration; (b) writes the final working set back.
  * The result is the same unique minimiser as a cold solve (the QP is strictly convex); only the
  * iteration path is shorter.  Row order must follow the robots (row b belongs to robot b of every
- * call).  NULL switches warm starting off.  The largest size class (n_r > 128) always starts cold, and so
- * does qmpc_solve_commands (warm starting is wired into the record entry points). */
+ * call).  NULL switches warm starting off.  Warm-started solves take the one-kernel path in every size class (the
+ * decoupled engine of the 128- / 192-row classes starts cold); qmpc_solve_commands always starts cold (warm starting is
+ * wired into the record entry points). */
 #define QMPC_WS_SLOTS 64
 int qmpc_set_warm_start(qmpc_handle h, int32_t* ws_dev, int shift_steps);
 

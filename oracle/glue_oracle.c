@@ -90,7 +90,9 @@ void oracle_leg_command(const float geom[4], int leg, const float tauFF[3], cons
   for (int k = 0; k < 3; k++) /* J^T * footForce */
     legTorque[k] = legTorque[k] + ((J[k] * footForce[0] + J[3 + k] * footForce[1]) + J[6 + k] * footForce[2]);
   oracle_leg_ik(geom, leg, pDes, qDes);
-  for (int k = 0; k < 3; k++) tau[k] = kp_joint * (0.0f - q[k]) - kd_joint * qd[k] + legTorque[k];
+  /* LegController.cpp:147-154: `crtlParam(2) * (0.0 - q)` carries a double literal, so the term and the sum are double,
+   * rounded to float once on assignment; crtlParam(3) * qd is a float product */
+  for (int k = 0; k < 3; k++) tau[k] = (float)((double)kp_joint * (0.0 - (double)q[k]) - (double)(kd_joint * qd[k]) + (double)legTorque[k]);
 }
 
 /* Interpolation.h:27-67 */

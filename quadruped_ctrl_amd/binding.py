@@ -467,9 +467,11 @@ class BatchedConvexMPC:
         """Test hook: use only n slices of the overflow event pool (negative: all)."""
         self._check(self.lib.qmpc_set_debug_overflow_slices(self.h, int(n)), "qmpc_set_debug_overflow_slices")
 
-    def set_split(self, on):
-        """Decoupled sweep / engine kernels for the 128- and 192-row classes (default on)."""
-        self._check(self.lib.qmpc_set_split(self.h, int(bool(on))), "qmpc_set_split")
+    def set_split(self, mode):
+        """Decoupled sweep / engine kernels for the 128- and 192-row classes: 0 / False off, 1 automatic by batch
+        size (default), 2 / True always."""
+        mode = 2 if mode is True else (0 if mode is False else int(mode))
+        self._check(self.lib.qmpc_set_split(self.h, mode), "qmpc_set_split")
 
     def set_block_start(self, on):
         self._check(self.lib.qmpc_set_block_start(self.h, int(bool(on))), "qmpc_set_block_start")

@@ -103,7 +103,7 @@ struct qmpc_ctx {
   int* d_lists = nullptr;      // [3][max_batch] robot ids handed to classes 4, 2 and 3
   int* d_counts = nullptr;     // [2 sets][QMPC_COUNTERS] (layout in qmpc_device.h); ping-ponged between calls
   // decoupled path (sweep kernel -> work items -> engine kernel) of the 128- and 192-row classes: [0] class 2, [1] class 3
-  bool split = true;           // qmpc_set_split; QMPC_NO_SPLIT=1 in the environment switches it off at creation
+  int split = 1;               // qmpc_set_split: 0 off, 1 automatic (by batch size), 2 always; QMPC_NO_SPLIT=1 in the environment: 0 at creation
   double* d_wk_hinv[2] = {nullptr, nullptr};
   double* d_wk_xu[2] = {nullptr, nullptr};
   QmpcWorkHdr* d_wk_hdr[2] = {nullptr, nullptr};
@@ -219,7 +219,7 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 2 * (size_t)max_batch);
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
-    c->split = !(ns && ns[0] == '1');
+    c->split = (ns && ns[0] == '1') ? 0 : 1;
     const char* nb = std::getenv("QMPC_BLOCK");
     c->block = nb && nb[0] == '1';
   }
@@ -411,7 +411,8 @@ int qmpc_set_debug_overflow_slices(qmpc_handle c, int n) {
 
 int qmpc_set_split(qmpc_handle c, int on) {
   if (!c) return QMPC_ERR_ARG;
-  c->split = on != 0;
+  if (on < 0 || on > 2) return QMPC_ERR_ARG;
+  c->split = on;
   return QMPC_OK;
 }
 
@@ -635,7 +636,12 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     const bool listed = k > k0;
     // ---- decoupled path (128- and 192-row classes, exact solve, cold start): sweep kernel -> work items -> engine
     // kernel -> (rarely) the monolithic kernel on the robots the engine handed back
-    const bool split = c->split && (chain[k] == 2 || chain[k] == 3) && !P.admm_mode && !P.ws;
+    // (automatic: a small batch is latency-bound -- one workgroup per CU either way -- and the one-kernel path has one
+    //  launch and no trip through L2 on it: measured break-even ~300 robots in the 128-row class, below 128 in the
+    //  192-row class.  Decided by the HANDLE's size, not the call's: a robot's result does not depend on the batch it is
+    //  solved in -- the two paths agree to ~1e-14 relative, not bit for bit)
+    const bool big = c->split == 2 || c->max_batch >= (chain[k] == 2 ? 384 : 128);
+    const bool split = c->split && big && (chain[k] == 2 || chain[k] == 3) && !P.admm_mode && !P.ws;
     if (split) {
       const int sk = chain[k] == 2 ? 0 : 1;
       if (const int rc = ensure_split(c, chain[k])) return rc;

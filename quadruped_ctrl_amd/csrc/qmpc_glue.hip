@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void qmpc_leg_cmd_kernel(const QmpcLegGeom g, 
   // tau_*_ff[leg] = crtlParam(2) * (0 - q) - crtlParam(3) * qd + legTorque                   (:138-158)
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    tau[o3 + k] = c.kp_joint * (0.0f - c.q[o3 + k]) - c.kd_joint * c.qd[o3 + k] + lt[k];
+    // (LegController.cpp:147-154 writes `crtlParam(2) * (0.0 - q)` with a DOUBLE literal: the joint-PD term and the sum
+    //  are evaluated in double there and rounded to float once; kd * qd is a float product)
+    tau[o3 + k] = (float)((double)c.kp_joint * (0.0 - (double)c.q[o3 + k]) - (double)(c.kd_joint * c.qd[o3 + k]) + (double)lt[k]);
   if (q_des) {  // computeLegIK(_quadruped, commands[leg].pDes, &qDes, leg)                  (:137)
     float qd3[3];
     qmpc_leg_ik(g, leg, c.p_des[o3 + 0], c.p_des[o3 + 1], c.p_des[o3 + 2], qd3);

@@ -441,6 +441,7 @@ def test_long_horizons_vs_oracle(h, gait, B, mpc_factory):
     nst = (b["gait"] != 0).sum(1)
     assert 3 * nst.max() <= 192
     m = mpc_factory(b)
+    m.set_split(True)
     res, idx, worst, nact = _solver_parity_on_own_qp(m, b, lambda r: np.argsort(r["iters"])[-4:], nwsr=5000)
     assert ((res["status"] & 47) == 0).all()
     ref, nwsr, rc = O.solve_batch(b)
@@ -906,12 +907,36 @@ def test_decoupled_path_matches_one_kernel_path_and_qpoases(mk, name, mpc_factor
         assert np.array_equal(again["soln"], res["soln"]) and np.array_equal(again["status"], res["status"])
 
 
+def test_decoupled_path_automatic_mode_and_one_kernel_long_horizon(mpc_factory):
+    """qmpc_set_split(1) (default): small batches of the large classes take the one-kernel path (one launch less on a
+    latency-bound solve), large ones the decoupled path; both give the same answer.  The one-kernel path of the 192-row
+    class also assembles long horizons (it is where the engine hands robots back to)."""
+    b = W.make_standing(500, 10)
+    m = mpc_factory(b)
+    auto = m.solve(b, full=True)                      # 500 >= 384: decoupled
+    m.set_split(0)
+    one = m.solve(b, full=True)
+    assert ((auto["status"] & 47) == 0).all() and ((one["status"] & 47) == 0).all()
+    assert (one["status"] & 128).any() and not (auto["status"] & 128).any()     # (only the one-kernel path spills to its overflow pool)
+    scale = np.abs(one["soln"]).max(1).clip(1.0)
+    assert (np.abs(auto["soln"] - one["soln"]).max(1) / scale).max() < 1e-10
+    bl = W.make_long_horizon(40, 24, "trot")
+    ml = mpc_factory(bl)
+    a = ml.solve(bl, full=True)                       # 40 < 128: one-kernel path at horizon 24
+    ml.set_split(2)
+    c = ml.solve(bl, full=True)
+    assert ((a["status"] & 47) == 0).all() and ((c["status"] & 47) == 0).all()
+    scale = np.abs(a["soln"]).max(1).clip(1.0)
+    assert (np.abs(a["soln"] - c["soln"]).max(1) / scale).max() < 1e-10
+
+
 def test_decoupled_engine_block_start_same_minimiser(mpc_factory):
     """The engine's experimental block start (forced additions by all threads, removal of the rows with negative
     multipliers, then the normal iteration: qmpc_set_block_start) reaches the same unique minimiser as the plain
     iteration, on braking robots with 30 - 60 working-set changes and on calm ones with a handful."""
     for b in (W.make_standing(200, 10), W.make_standing(130, 14), W.make_standing(96, 10, calm=True)):
         m = mpc_factory(b)
+        m.set_split(True)
         base = m.solve(b, full=True)
         m.set_block_start(True)
         blk = m.solve(b, full=True)
@@ -929,6 +954,7 @@ def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
     Test hook: the capacity cut to 12 events."""
     b = W.make_standing(200, 10)
     m = mpc_factory(b)
+    m.set_split(True)      # (always, also below the batch size the automatic mode starts at)
     base = m.solve(b, full=True)
     assert ((base["status"] & 47) == 0).all() and not (base["status"] & 16).any()
     m.set_debug_engine_events(12)
@@ -995,7 +1021,9 @@ def test_result_does_not_depend_on_the_batch_around_a_robot(case, mpc_factory):
         extra += [big[:6], big[-12:]]
     pick = np.unique(np.concatenate([rng.choice(B, 24, replace=False)] + extra))
     sub = _take(b, pick)
-    m2 = mpc_factory(sub)
+    # (a handle of the same size: which path the large classes take is a property of the handle -- its max_batch --
+    #  never of the size of a call, include/qmpc.h qmpc_set_split)
+    m2 = mpc_factory(sub, max_batch=B)
     if jcqp:
         m2.settings_jcqp(jcqp, **kw)
     small = m2.solve(sub, full=True)
