@@ -1323,6 +1323,14 @@ def test_warm_start_rollout_same_answer(gait, h, mpc_factory):
         assert ((rc["status"] & 47) == 0).all() and ((rw["status"] & 47) == 0).all()
         err = np.abs(rw["soln"] - rc["soln"]).max(1) / np.maximum(np.abs(rc["soln"]).max(1), 1.0)
         assert err.max() < 1e-9, (c, err.max())
+        if c in (1, 4, 7):
+            # ... and against the ORACLE, not only against the cold kernel: the warm-started forces vs the
+            # reference pipeline (float assembly restatement + the reference's qpOASES) on a sample of the robots
+            so = list(range(0, B, 8))
+            ref, _, orc = O.solve_batch(b, so)
+            assert (orc == 0).all()
+            eo, bd = rel_f0(rw["grf"][so], ref), bound_for(b, so)
+            assert (eo < bd).all(), (c, eo.max())
         w = ws.cpu().numpy()
         nact = (w >= 0).sum(1)
         assert (w < 20 * h).all()

@@ -24,6 +24,17 @@ run standing_h10 --workload standing --horizon 10
 run standing_h14 --workload standing --horizon 14
 run standing_h16 --workload standing --horizon 16
 run trot_h16 --config 3
+# long horizons (the 192-row class + the decoupled engine): trot at 24 segments, bounding-type gait at 36
+python $R/bench.py --steps 100 --workload long-trot --horizon 24 --no-cpu-all-cores > $OUT/bench_long_trot_h24.json 2> $OUT/bench_long_trot_h24.err
+python $R/bench.py --steps 50 --workload long-bound --horizon 36 --no-cpu-all-cores > $OUT/bench_long_bound_h36.json 2> $OUT/bench_long_bound_h36.err
+# the same standing workloads on the one-kernel path (before / after of the decoupled path in ONE profile set)
+for hh in 10 14 16; do
+  QMPC_NO_SPLIT=1 python $R/bench.py --steps 200 --workload standing --horizon $hh --no-cpu-baseline --no-pipelined > $OUT/bench_standing_h${hh}_one_kernel.json 2>/dev/null
+done
+python $R/tools/split_check.py 1024 2>/dev/null | grep -v "^{" | grep -v amdgpu > $OUT/split_check.txt
+python $R/tools/engine_phase.py s10 256 2>/dev/null | grep -v amdgpu > $OUT/engine_phases.txt
+python $R/tools/engine_phase.py s14 256 2>/dev/null | grep -v amdgpu >> $OUT/engine_phases.txt
+python $R/tools/chunk_sweep.py 2>/dev/null | grep -v amdgpu > $OUT/chunk_sweep.txt
 # bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
 for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
 for a in "--config 4 --batch 8192" "--workload standing --horizon 10 --batch 1024" "--workload standing --horizon 16 --batch 1024"; do python $R/tools/class_stats.py $a; done > $OUT/class_stats.txt 2>/dev/null
