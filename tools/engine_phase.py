@@ -16,6 +16,7 @@ mpc.setup(b["dt"], b["horizon"], b["mu"], b["f_max"])
 nst = (b["gait"] != 0).sum(1)
 mpc.set_max_stance(int(nst.max()))
 mpc.set_min_stance(int(nst.min()))
+mpc.set_split(2)   # the decoupled path whatever the handle's size
 d = mpc.upload(b)
 o = mpc.alloc_outputs(B)
 inp, out = mpc.make_args(d, o)
