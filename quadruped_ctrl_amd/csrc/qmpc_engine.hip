@@ -45,9 +45,8 @@ struct ECfg {
   static constexpr int KEV = NH * MAXL + MAXE;    // capacity
   static constexpr int EV = NP + KS;
   static_assert(MAXE >= MAXL && MAXE <= 64, "engine-held events");
-  // block start: constraints factorised at once (their records M -> Z~ live in the engine wave's event pool; the
-  // Cholesky factor is held one row per lane of one wave, KB doubles per lane)
-  static constexpr int KB = (MAXE < 40 ? MAXE : 40) & ~1;
+  // block start: records it may leave -- what the holders' registers take afterwards (its LDS is the engine wave's pool)
+  static constexpr int MAXB = (NH * MAXL < MAXE ? NH * MAXL : MAXE) & ~1;
   static_assert(NSL <= QMPC_WK_SLOTS_MAX, "stance slots of a work item");
   static_assert(5 * NSL <= 1024, "constraint id in ten bits of the selection key");
 };
@@ -134,38 +133,61 @@ __device__ __forceinline__ void dispatch_blocks(int q1, int q2, F&& f) {
   });
 }
 
+// f(integral_constant<V>) for the run-time value v in [LO, HI): a binary tree of wave-uniform branches (log2 levels)
+template <int LO, int HI>
+struct Pick {
+  template <class F>
+  static __device__ __forceinline__ void run(int v, F&& f) {
+    if constexpr (HI - LO == 1) {
+      f(std::integral_constant<int, LO>{});
+    } else {
+      constexpr int MID = (LO + HI) / 2;
+      if (v < MID) Pick<LO, MID>::run(v, f);
+      else Pick<MID, HI>::run(v, f);
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------- block start
 // The dual active set adds ONE constraint per iteration, and a robot braking to a stand ends with 30+ rows at a bound:
 // a serial chain of 30+ iterations of ~5 k cycles, each with a selection, a ratio test and two barrier rounds with the
 // holders.  Most of those rows are known early: the rows violated at the unconstrained minimiser x_u are, almost
 // without exception, active at the solution (precision 0.96 - 1.00).  So the iteration starts from a BLOCK
-// of forced additions, made by ALL threads of the workgroup with the records in LDS (the engine wave's event pool):
+// of forced changes made by ALL threads of the workgroup:
 //   round r = 1 .. QMPC_BLK_ROUNDS: the most violated row of every stance foot-step at the current x (not in W yet),
 //   each added as in a full Goldfarb-Idnani step but WITHOUT search and ratio test:
-//       y_e = z~_e^T c (thread e),  z = H^-1 c - sum_add y z~ + sum_drop y z~,  r = sum y g~  (thread per entry),
-//       delta = c^T z,  t = -(c^T x - rhs) / delta,  x += t z,  lambda_W -= t r,  lambda_p = t,  record (z, -r, 1) / sqrt(delta)
-//   -- ~0.8 k + 12 cycles per earlier record instead of ~5 k per iteration; x is then the minimiser on W as equalities;
-//   afterwards the rows whose multiplier came out negative leave, most negative first (drop records with the repair
-//   step: x -= (lambda_l / gamma) N*_l, lambda -= (lambda_l / gamma) S^-1[:, l]), again by all threads.
+//       y_e = z~_e^T c,  z = H^-1 c - sum y z~,  r = sum y g~,  delta = c^T z,  t = -(c^T x - rhs) / delta,
+//       x += t z,  lambda_W -= t r,  lambda_p = t,  new record (z, -r, 1) / sqrt(delta);
+//   x is then the minimiser on W as equalities; afterwards the rows whose multiplier came out negative leave, most
+//   negative first (drop records with the repair step: x -= (lambda_l / gamma) N*_l, lambda -= (lambda_l / gamma) S^-1[:, l]).
+// Data layout of the phase: thread t owns ENTRY t of every record (t < NP: variable t of z~; t >= NP: slot t - NP of g~)
+// in REGISTERS (`col`, statically indexed), and a TRANSPOSED copy of the records sits in LDS (`Rt[t][e]`: entry t of all
+// records contiguous) -- so y for all records is two contiguous broadcast vectors (16-byte loads), and the accumulation
+// over the records is one fma per record on the thread's own registers: no pass over record-major data in LDS (measured
+// before: ~95 cycles per record and forced change, latency-bound).  Two LDS-only barriers per forced change.
 // What comes out is a genuine Goldfarb-Idnani state (x optimal on W, multipliers >= 0, the projected inverse as rank-1
-// records): the holders take their share of the records into registers and the normal iteration finishes the job --
-// same unique minimiser (tools/block_proto.py: braking at horizon 10, 34 iterations -> 4 rounds, ~5 drops, ~4 iterations).
+// records): the holders take the records into their registers and the normal iteration finishes the job -- same unique
+// minimiser (tools/block_proto.py: braking at horizon 10, 34 iterations -> 4 rounds, ~5 removals, ~4 iterations).
 #ifndef QMPC_BLK_ROUNDS
 #define QMPC_BLK_ROUNDS 4
 #endif
 template <class C>
 __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const GlobalF64* const Hi, const GlobalF64* const xu,
                                             const int n, const int nst, const int max_changes) {
-  constexpr int SQ = C::SQ, NP = C::NP, LD = C::NP, NT = C::NT, EV = C::EV, KS = C::KS, MAXE = C::MAXE;
+  constexpr int SQ = C::SQ, NP = C::NP, LD = C::NP, NT = C::NT, EV = C::EV, KS = C::KS, NH = C::NH;
+  constexpr int MAXB = C::MAXB;
   constexpr int NCMAX = 12;  // candidates added per round
   static_assert(EV <= NT, "one thread per record entry");
   const QmpcParams& P = S.par;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   auto& B = S.bk;
-  double(*const R)[EV] = S.epool;  // record e: z~_e in [0, NP), g~_e in [NP, NP + KS)
-  double* const T = S.stage;       // the vector being built (z | r)
+  double(*const Rt)[MAXB] = reinterpret_cast<double(*)[MAXB]>(&S.epool[0][0]);  // Rt[entry][record]
+  static_assert(sizeof(double) * EV * MAXB <= sizeof(S.epool), "transposed records fit the engine wave's pool");
+  double* const T = S.stage;  // the vector being built (z | r)
   const double mi = P.mu_inv;
+  const bool isvar = tid < NP, isslot = tid >= NP && tid < EV, isent = tid < EV;
+  const int w = tid - NP;  // slot of a slot thread
   if (tid == 0) {
     B.ne = 0;
     B.nadd = 0;
@@ -175,39 +197,23 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
     B.wcid[k] = -1;
     B.lam[k] = 0.0;
   }
+  if (isent) {
+#pragma unroll
+    for (int e = 0; e < MAXB; e += 2) st2(&Rt[tid][e], 0.0, 0.0);
+  }
+  double col[MAXB];  // this thread's entry of every record
+#pragma unroll
+  for (int e = 0; e < MAXB; ++e) col[e] = 0.0;
   __syncthreads();
-  const bool isvar = tid < NP, isslot = tid >= NP && tid < EV;
-  const int w = tid - NP;  // slot of a slot thread
-  // one accumulation over the records: acc += yv[e] * R[e][tid], four records per trip
-  auto accumulate = [&](const double* yv, int ne, double acc) __attribute__((always_inline)) {
-    // (eight records per trip, two partial sums: the loop is bound by LDS latency, not by its arithmetic)
-    int e = 0;
-    double acc2 = 0.0;
-#pragma unroll 1
-    for (; e + 8 <= ne; e += 8) {
-      const F64x2 ya = ld2(yv + e), yb = ld2(yv + e + 2), yc = ld2(yv + e + 4), yd = ld2(yv + e + 6);
-      const double r0 = R[e][tid], r1 = R[e + 1][tid], r2 = R[e + 2][tid], r3 = R[e + 3][tid];
-      const double r4 = R[e + 4][tid], r5 = R[e + 5][tid], r6 = R[e + 6][tid], r7 = R[e + 7][tid];
-      acc = __builtin_fma(ya.x, r0, acc);
-      acc2 = __builtin_fma(ya.y, r1, acc2);
-      acc = __builtin_fma(yb.x, r2, acc);
-      acc2 = __builtin_fma(yb.y, r3, acc2);
-      acc = __builtin_fma(yc.x, r4, acc);
-      acc2 = __builtin_fma(yc.y, r5, acc2);
-      acc = __builtin_fma(yd.x, r6, acc);
-      acc2 = __builtin_fma(yd.y, r7, acc2);
-    }
-    if (e + 4 <= ne) {
-      const F64x2 ya = ld2(yv + e), yb = ld2(yv + e + 2);
-      const double r0 = R[e][tid], r1 = R[e + 1][tid], r2 = R[e + 2][tid], r3 = R[e + 3][tid];
-      acc = __builtin_fma(ya.x, r0, acc);
-      acc2 = __builtin_fma(ya.y, r1, acc2);
-      acc = __builtin_fma(yb.x, r2, acc);
-      acc2 = __builtin_fma(yb.y, r3, acc2);
-      e += 4;
-    }
-    for (; e < ne; ++e) acc = __builtin_fma(yv[e], R[e][tid], acc);
-    return acc + acc2;
+  // the new record's entry goes into register [ne] (a run-time index: one case per register, kept apart by a dummy
+  // instruction -- see the holders' ingest) and into the transposed copy
+  auto put_entry = [&](int ne, double v) __attribute__((always_inline)) {
+    Pick<0, MAXB>::run(ne, [&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      col[e] = v;
+      asm volatile("; record register %0" ::"n"(e));
+    });
+    Rt[tid][ne] = v;
   };
   bool stop = false;
   for (int round = 0; round < QMPC_BLK_ROUNDS && !stop; ++round) {
@@ -264,30 +270,60 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
       const double a1 = (ty < 4) ? ((ty & 1) ? -mi : mi) : -1.0, a2 = (ty < 4) ? 1.0 : 0.0;
       zc[ci] = (isvar && tid < n) ? __builtin_fma(a2, Hi[(size_t)j2 * LD + tid], a1 * Hi[(size_t)j1 * LD + tid]) : 0.0;
     });
-    Upto<0, NCMAX>::run(nc, [&](auto cic) __attribute__((always_inline)) {
-      constexpr int ci = decltype(cic)::value;
-      if (stop) return;
+#pragma unroll 1
+    for (int ci = 0; ci < nc && !stop; ++ci) {
       const int ne = B.ne, q = B.nadd;
-      if (ne >= MAXE || q >= KS || ne >= max_changes) {  // uniform: no room / iteration limit -- the normal iteration goes on
+      if (ne >= MAXB || q >= KS || ne >= max_changes) {  // uniform: no room / iteration limit -- the normal iteration goes on
         stop = true;
-        return;
+        break;
       }
+#ifdef QMPC_BLK_STAMP
+      long long* const bclk = (P.dbg_clk && tid == 0 && ne == QMPC_BLK_STAMP) ? P.dbg_clk + (size_t)S.rid * 16 : nullptr;
+      if (bclk) bclk[0] = clock64();
+#endif
       // ---- forced addition of row id into slot q
       const int id = B.cand[ci];
       const int slot = id / 5, ty = id - 5 * slot, j0 = 3 * slot;
       const int j1 = (ty < 4) ? j0 + (ty >> 1) : j0 + 2, j2 = j0 + 2;
       const double a1 = (ty < 4) ? ((ty & 1) ? -mi : mi) : -1.0, a2 = (ty < 4) ? 1.0 : 0.0;
       const double rhs = (ty == 4) ? -(double)S.fmaxk[slot] : 0.0;
-      if (tid < ne) {
-        const double y = __builtin_fma(a2, R[tid][j2], a1 * R[tid][j1]);
-        B.Y[tid] = y;
-        B.Ys[tid] = (B.sign[tid] > 0) ? -y : y;
+      const double sp = __builtin_fma(a2, S.xl[j2], a1 * S.xl[j1]) - rhs;  // (x is stable until step 2)
+      // (every record is an ADD record while the rounds last -- removals come after them)
+      double zc_ci = 0.0;
+      StaticFor<0, NCMAX>::run([&](auto cc) __attribute__((always_inline)) {
+        if (decltype(cc)::value == ci) zc_ci = zc[decltype(cc)::value];
+      });
+      if (isent) {
+        const double sg = isvar ? -1.0 : 1.0;
+        double acc = isvar ? zc_ci : 0.0, acc2 = 0.0;
+        const double* const r1 = Rt[j1];
+        const double* const r2 = Rt[j2];
+        // eight records per group: their 16-byte broadcast loads in flight together, ONE wait (behind a wave-uniform
+        // branch per record the loads cannot be hoisted and every step waits its own LDS round trip: 1.8 k cycles at 20 records)
+        Upto<0, (MAXB + 7) / 8>::run((ne + 7) >> 3, [&](auto gc) __attribute__((always_inline)) {
+          constexpr int e0 = 8 * decltype(gc)::value;
+          constexpr int NPR = (MAXB - e0 >= 8) ? 4 : (MAXB - e0) / 2;
+          F64x2 p[NPR], qq[NPR];
+#pragma unroll
+          for (int u = 0; u < NPR; ++u) {
+            p[u] = ld2(r1 + e0 + 2 * u);  // (records past the last one are zero)
+            qq[u] = ld2(r2 + e0 + 2 * u);
+          }
+#pragma unroll
+          for (int u = 0; u < NPR; ++u) {
+            acc = __builtin_fma(sg * __builtin_fma(a2, qq[u].x, a1 * p[u].x), col[e0 + 2 * u], acc);
+            acc2 = __builtin_fma(sg * __builtin_fma(a2, qq[u].y, a1 * p[u].y), col[e0 + 2 * u + 1], acc2);
+          }
+        });
+        T[tid] = acc + acc2;
       }
-      const double sp = __builtin_fma(a2, S.xl[j2], a1 * S.xl[j1]) - rhs;  // (x is stable until step 3)
+#ifdef QMPC_BLK_STAMP
+      if (bclk) bclk[3] = clock64();
+#endif
       lds_barrier();
-      if (isvar) T[tid] = accumulate(B.Ys, ne, zc[ci]);
-      else if (isslot) T[tid] = accumulate(B.Y, ne, 0.0);
-      lds_barrier();
+#ifdef QMPC_BLK_STAMP
+      if (bclk) bclk[4] = clock64();
+#endif
       const double delta = __builtin_fma(a2, T[j2], a1 * T[j1]);
       const double cn = __builtin_fma(a2 * a2, S.D[j2], a1 * a1 * S.D[j1]);
       if (delta > 1e-11 * cn) {  // uniform (else: the row depends on the ones in W, e.g. the pyramid's apex: skipped)
@@ -301,12 +337,12 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
         }
         if (isvar) {
           const double z = T[tid];
-          R[ne][tid] = z * sq;
+          put_entry(ne, z * sq);
           if (tid < n) S.xl[tid] = __builtin_fma(tt, z, S.xl[tid]);
         } else if (isslot) {
           const double r = T[tid];
           const bool active = B.wcid[w] >= 0;
-          R[ne][tid] = (w == q) ? sq : (active ? -r * sq : 0.0);
+          put_entry(ne, (w == q) ? sq : (active ? -r * sq : 0.0));
           if (active) B.lam[w] = __builtin_fma(-tt, r, B.lam[w]);
           if (w == q) {
             B.lam[w] = tt;
@@ -319,8 +355,14 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
           B.nadd = q + 1;
         }
       }
+#ifdef QMPC_BLK_STAMP
+      if (bclk) bclk[5] = clock64();
+#endif
       lds_barrier();
-    });
+#ifdef QMPC_BLK_STAMP
+      if (bclk) bclk[7] = clock64();
+#endif
+    }
   }
   // ---- rows whose multiplier came out negative leave, most negative first
   while (true) {
@@ -343,16 +385,32 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
     }
     lds_barrier();
     const int l = B.dl, ne = B.ne;
-    if (l < 0 || ne >= MAXE || ne >= max_changes) break;  // uniform (rows still negative are dropped by the engine wave's own loop)
-    if (tid < ne) {
-      const double y = R[tid][NP + l];
-      B.Y[tid] = y;
-      B.Ys[tid] = (B.sign[tid] > 0) ? y : -y;
-    }
+    if (l < 0 || ne >= MAXB || ne >= max_changes) break;  // uniform (rows still negative are dropped by the engine wave's own loop)
     const double laml = B.lam[l];
-    lds_barrier();
-    if (isvar) T[tid] = accumulate(B.Y, ne, 0.0);        // u = N*_l
-    else if (isslot) T[tid] = accumulate(B.Ys, ne, 0.0); // sc = S^-1[:, l]
+    if (isent) {
+      // u = N*_l = sum g~_e[l] z~_e (variable entries), sc = S^-1[:, l] = sum +-g~_e[l] g~_e (slot entries; - for drop records)
+      double acc = 0.0, acc2 = 0.0;
+      const double* const rl = Rt[NP + l];
+      Upto<0, (MAXB + 7) / 8>::run((ne + 7) >> 3, [&](auto gc) __attribute__((always_inline)) {
+        constexpr int e0 = 8 * decltype(gc)::value;
+        constexpr int NPR = (MAXB - e0 >= 8) ? 4 : (MAXB - e0) / 2;
+        F64x2 y[NPR];
+        int sgn[2 * NPR];
+#pragma unroll
+        for (int u = 0; u < NPR; ++u) {
+          y[u] = ld2(rl + e0 + 2 * u);
+          sgn[2 * u] = B.sign[e0 + 2 * u];
+          sgn[2 * u + 1] = B.sign[e0 + 2 * u + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < NPR; ++u) {
+          const double s0 = (isslot && sgn[2 * u] < 0) ? -y[u].x : y[u].x, s1 = (isslot && sgn[2 * u + 1] < 0) ? -y[u].y : y[u].y;
+          acc = __builtin_fma(s0, col[e0 + 2 * u], acc);
+          acc2 = __builtin_fma(s1, col[e0 + 2 * u + 1], acc2);
+        }
+      });
+      T[tid] = acc + acc2;
+    }
     lds_barrier();
     const double gamma = T[NP + l];
     if (!(gamma > 0.0)) {  // uniform: numerically lost S^-1[l][l] > 0 -- the robot is handed back
@@ -367,19 +425,24 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
       e = __builtin_fma(-gamma * sg, sg, 1.0);
       sg = __builtin_fma(0.5 * sg, e, sg);
     }
-    if (tid < ne) R[tid][NP + l] = 0.0;  // slot l leaves: its column of every earlier g~ is cleared
     if (isvar) {
       const double u = T[tid];
-      R[ne][tid] = u * sg;
+      put_entry(ne, u * sg);
       if (tid < n) S.xl[tid] = __builtin_fma(-coef, u, S.xl[tid]);
     } else if (isslot) {
       const double sc = T[tid];
       const bool active = B.wcid[w] >= 0 && w != l;
-      R[ne][tid] = active ? -sc * sg : 0.0;
-      if (active) B.lam[w] = __builtin_fma(-coef, sc, B.lam[w]);
       if (w == l) {
+        // slot l leaves: its column of every earlier g~ is cleared -- this thread's registers and its row of the copy
+#pragma unroll
+        for (int e = 0; e < MAXB; ++e) col[e] = 0.0;
+#pragma unroll
+        for (int e = 0; e < MAXB; e += 2) st2(&Rt[tid][e], 0.0, 0.0);
         B.wcid[w] = -1;
         B.lam[w] = 0.0;
+      } else {
+        put_entry(ne, active ? -sc * sg : 0.0);
+        if (active) B.lam[w] = __builtin_fma(-coef, sc, B.lam[w]);
       }
     }
     if (tid == 0) {
@@ -434,11 +497,9 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
   __syncthreads();
   const int bkev = S.bk.ne;  // records the block start left in the engine wave's pool (record e = event e)
   if (dbg_clk && tid == 0) dbg_clk[13] = clock64();
-  // event e: dealt round-robin over the engine wave (owner 0, LDS) and the holders (owners 1..NH, registers) while the
-  // holders have room, then to the engine wave's LDS pool
-  auto ev_owner = [](int e) __attribute__((always_inline)) { return e < C::NRR ? e % (NH + 1) : 0; };
-  auto ev_index = [](int e) __attribute__((always_inline)) { return e < C::NRR ? e / (NH + 1) : MAXL + (e - C::NRR); };
-
+  // Events are dealt to whoever holds the fewest: the engine wave (owner 0, its LDS pool, MAXE records) or a holder
+  // (owners 1..NH, MAXL register slots each); the engine wave keeps the counts.  The block start's records all go to the
+  // holders (record e -> holder 1 + e mod NH, registers [e / NH]): its LDS is the engine wave's pool.
   if (wv == 0) {
     // =============================================================== the engine wave
     const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
@@ -465,6 +526,9 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     int khw = 0, status = 0, nev = 0, iters = 0;
     int nle = 0;                        // events in the engine wave's own LDS pool
     unsigned long long dropme = 0ull;   // ... that are drop events
+    int cnt[NH + 1];                    // events held by owner o (0 = this wave's pool = nle)
+#pragma unroll
+    for (int o = 0; o <= NH; ++o) cnt[o] = 0;
     bool retry = false;
     if (bkev > 0) {
       // ---- state left by the block start: x (already in xl), the working set and its multipliers by slot, membership
@@ -489,24 +553,9 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       nev = bkev;
       iters = bkev;  // (every forced addition / removal of the block start is a working-set change like an iteration's)
       if (S.bk.fail != 0) retry = true;
-      lds_barrier();  // the holders have read their records
-      for (int li = 0; li * (NH + 1) < bkev; ++li) {
-        const int c = li * (NH + 1);
-        if (c != li) {
-          double tz[RE], tg[KQ];
 #pragma unroll
-          for (int q = 0; q < RE; ++q) tz[q] = S.epool[c][lane + 64 * q];
-#pragma unroll
-          for (int k = 0; k < KQ; ++k) tg[k] = S.epool[c][NP + lane + 64 * k];
-#pragma unroll
-          for (int q = 0; q < RE; ++q) S.epool[li][lane + 64 * q] = tz[q];
-#pragma unroll
-          for (int k = 0; k < KQ; ++k) S.epool[li][NP + lane + 64 * k] = tg[k];
-        }
-        if (S.bk.sign[c] < 0) dropme |= (1ull << li);
-        nle = li + 1;
-      }
-      __builtin_amdgcn_wave_barrier();
+      for (int o = 1; o <= NH; ++o) cnt[o] = (bkev > o - 1) ? (bkev - (o - 1) + NH - 1) / NH : 0;
+      lds_barrier();  // the holders have taken the records (the phase's LDS is this wave's event pool from here on)
     }
     int p_e = 0, psl = 0, pty = 0, pj1 = 0, pj2 = 0;
     double pa1 = 0.0, pa2 = 0.0, p_rhs = 0.0, lp = 0.0;
@@ -572,8 +621,27 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     // the new event goes to its owner: straight into the engine wave's LDS pool, or staged for a holder (which takes it
     // into its registers at the next (A)); clear_slot >= 0: that working-set slot was dropped -- its column of every
     // g~ is cleared (the holders do theirs when they see the flag)
+    auto has_room = [&]() __attribute__((always_inline)) {
+      bool room = false;
+#pragma unroll
+      for (int o = 0; o <= NH; ++o) room |= cnt[o] < ((o == 0) ? MAXE : MAXL);
+      return room && nev < kev;
+    };
     auto place_event = [&](const double (&zv)[RE], const double (&gv)[KQ], bool is_drop, int clear_slot) __attribute__((always_inline)) {
-      const int owner = ev_owner(nev), li = ev_index(nev);
+      // the owner with the fewest events that still has room (ties: the lowest index); has_room() was checked before
+      int owner = -1, best = 1 << 30;
+#pragma unroll
+      for (int o = 0; o <= NH; ++o) {
+        const int cap = (o == 0) ? MAXE : MAXL;
+        if (cnt[o] < cap && cnt[o] < best) {
+          best = cnt[o];
+          owner = o;
+        }
+      }
+      const int li = best;
+#pragma unroll
+      for (int o = 0; o <= NH; ++o)
+        if (o == owner) cnt[o] += 1;
       double* const dst = (owner == 0) ? S.epool[li] : S.stage;
 #pragma unroll
       for (int q = 0; q < RE; ++q) dst[lane + 64 * q] = zv[q];
@@ -695,7 +763,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       }
       const double wmax = wave_max_pos_f64(worst);
       if (!(wmax > 0.0)) break;
-      if (nev >= kev || iters >= max_iter) {
+      if (!has_room() || iters >= max_iter) {
         retry = true;
         break;
       }
@@ -714,6 +782,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       khw = __builtin_amdgcn_readfirstlane(khw);
       nev = __builtin_amdgcn_readfirstlane(nev);
       nle = __builtin_amdgcn_readfirstlane(nle);
+#pragma unroll
+      for (int o = 0; o <= NH; ++o) cnt[o] = __builtin_amdgcn_readfirstlane(cnt[o]);
       status = __builtin_amdgcn_readfirstlane(status);
       p_e = __builtin_amdgcn_readfirstlane(p_e);
       psl = __builtin_amdgcn_readfirstlane(psl);
@@ -722,7 +792,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       pj2 = __builtin_amdgcn_readfirstlane(pj2);
       QMPC_ESTAMP(0);
       // ---- room for one more event?  Every pass leaves exactly one (add or drop)
-      if (nev >= kev) {
+      if (!has_room()) {
         retry = true;
         break;
       }
@@ -921,18 +991,20 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     int nloc = 0, hround = 0;
     unsigned long long dropm = 0ull;  // local events that are drop events
     if (bkev > 0) {
-      // the block start's records: event e belongs to owner e mod (NH + 1), registers [e / (NH + 1)]
-      nloc = (bkev > wv) ? (bkev - wv + NH) / (NH + 1) : 0;
+      // the block start's records (transposed in LDS: Rt[entry][record]): record e goes to holder 1 + e mod NH,
+      // registers [e / NH]
+      const double(*const Rt)[C::MAXB] = reinterpret_cast<const double(*)[C::MAXB]>(&S.epool[0][0]);
+      nloc = (bkev > wv - 1) ? (bkev - (wv - 1) + NH - 1) / NH : 0;
       Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
         constexpr int li = decltype(lic)::value;
-        const int c = li * (NH + 1) + wv;
+        const int e = li * NH + (wv - 1);
 #pragma unroll
-        for (int q = 0; q < RE; ++q) zt[li][q] = S.epool[c][lane + 64 * q];
+        for (int q = 0; q < RE; ++q) zt[li][q] = Rt[lane + 64 * q][e];
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) gt[li][k] = S.epool[c][NP + lane + 64 * k];
-        if (S.bk.sign[c] < 0) dropm |= (1ull << li);
+        for (int k = 0; k < KQ; ++k) gt[li][k] = Rt[NP + lane + 64 * k][e];
+        if (S.bk.sign[e] < 0) dropm |= (1ull << li);
       });
-      lds_barrier();  // (the engine wave compacts its own records after this)
+      lds_barrier();  // (the phase's LDS becomes the engine wave's event pool after this)
     }
     while (true) {
       lds_barrier();  // (A)
