@@ -1,26 +1,27 @@
 // qmpc_engine.hip -- the CONSUMER half of the decoupled path: the dual active set (Goldfarb-Idnani, event form)
 // on an explicit inverse that lives in global memory, for the size classes whose robots iterate long
-// (128- and 192-row classes; the long-horizon producer uses the same engine).
+// (128- and 192-row classes, horizons up to 36 segments in the latter).
 //
 // What it replaces in the reference: the qpOASES call of solve_mpc (src/MPC_Ctrl/SolverMPC.cpp:527-557: cold
 // QProblem::init on H_red, g_red, A_red, then q_soln scatter) -- same unique minimiser (H is positive definite).
 //
 // Why a second engine.  In the monolithic kernel (qmpc_kernels.hip) a robot of the large classes holds
 // a whole CU -- the packed inverse fills its LDS -- while ONE of its 8 / 12 waves iterates (73 % of the wave-cycles
-// parked, PMC).  Here the producer (qmpc_sweep_kernel, or the Riccati producer for long horizons) writes H^-1 to an
-// L2 / Infinity-Cache resident work item and leaves; this kernel runs one robot per small workgroup, several per CU:
+// parked, PMC).  Here the producer (qmpc_sweep_kernel) writes H^-1 to an L2 / Infinity-Cache resident work item and
+// leaves; this kernel runs one robot per small workgroup (two per CU in the 128-row class):
 //   * wave 0 is the ENGINE: x, multipliers, working set in registers (lane = variable / stance slot / working slot),
 //     the two columns of H^-1 an iteration needs are two or three coalesced row loads (the matrix is symmetric);
 //   * waves 1..NH are event HOLDERS: the rank-1 events (z~, g~) that represent the projected inverse
 //         P = H^-1 - sum_add z~ z~^T + sum_drop z~ z~^T,   N* = sum z~ g~^T,   S^-1 = sum_add g~ g~^T - sum_drop g~ g~^T
-//     never leave the REGISTER FILE: event e lives in holder 1 + e mod NH, registers [e / NH] (RE + KQ doubles per
-//     lane and event, statically indexed).  An iteration's accumulation z -= +-y z~, r += y g~ (y = z~^T c_p) runs in
-//     all holders at once on their own events, operands by readlane -- no event pool in LDS or global memory, no
-//     loads at all in the loop that bounds the monolithic engine (~22 cycles per load instruction whoever issues it).
-//     Two workgroup barriers per iteration carry the request and the partial sums (fixed split, fixed order of the
-//     final sum: results do not depend on timing).
-// A robot that needs more events than the holders' registers take (NH * MAXL), or whose projected inverse loses
+//     never leave the REGISTER FILE: a new event goes to whoever holds the fewest -- a holder (MAXL statically indexed
+//     register slots of RE + KQ doubles per lane) or the engine wave itself (MAXE records in LDS: it is idle while the
+//     holders work).  An iteration's accumulation z -= +-y z~, r += y g~ (y = z~^T c_p) runs in all waves at once on
+//     their own events, the holders' operands by readlane -- no event pool in global memory, no spill / compaction
+//     machinery.  Two LDS-only workgroup barriers per iteration carry the request and the partial sums (fixed split,
+//     fixed order of the final sum: results do not depend on timing).
+// A robot that needs more events than registers + LDS hold (NH * MAXL + MAXE), or whose projected inverse loses
 // definiteness numerically, is handed back to the monolithic kernel of its class through a list (QMPC_ST_FALLBACK).
+// block_start (experimental, off by default): forced additions of candidate sets by all threads before the iteration.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
