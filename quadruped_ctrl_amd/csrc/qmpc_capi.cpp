@@ -107,6 +107,8 @@ struct qmpc_ctx {
   double* d_wk_hinv[2] = {nullptr, nullptr};
   double* d_wk_xu[2] = {nullptr, nullptr};
   QmpcWorkHdr* d_wk_hdr[2] = {nullptr, nullptr};
+  int* d_wk_order[2] = {nullptr, nullptr};
+  double* d_wk_ovf[2] = {nullptr, nullptr};  // engine kernels' overflow event pools (one slice per resident workgroup)  // [QMPC_ORDER_BUCKETS][max_batch] item indices, hardest robots first
   int wk_cap[2] = {0, 0};
   int* d_fb_lists = nullptr;   // [2][max_batch] robots the engine kernels hand back
   // chunked launches of the decoupled path: sweep kernels of consecutive chunks on aux[0], engine kernels alternating
@@ -261,6 +263,8 @@ int qmpc_destroy(qmpc_handle h) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
       if (h->d_wk_hdr[k]) hipFree(h->d_wk_hdr[k]);
+      if (h->d_wk_order[k]) hipFree(h->d_wk_order[k]);
+      if (h->d_wk_ovf[k]) hipFree(h->d_wk_ovf[k]);
     }
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->order_ev) hipEventDestroy(h->order_ev);
@@ -491,6 +495,14 @@ int ensure_split(qmpc_ctx* c, int rb) {
   HIP_TRY(c, hipMalloc(&c->d_wk_hinv[k], sizeof(double) * cap * ld * ld));
   HIP_TRY(c, hipMalloc(&c->d_wk_xu[k], sizeof(double) * cap * ld));
   HIP_TRY(c, hipMalloc(&c->d_wk_hdr[k], sizeof(QmpcWorkHdr) * cap));
+  HIP_TRY(c, hipMalloc(&c->d_wk_order[k], sizeof(int) * QMPC_ORDER_BUCKETS * cap));
+  {
+    // (the engine grid never exceeds the resident workgroups: slice = blockIdx.x)
+    size_t wgs = (size_t)qmpc_engine_resident(rb);
+    if (wgs == 0 || wgs > cap) wgs = cap;
+    const size_t ev = rb == 2 ? 128 + 64 : 192 + 128;
+    HIP_TRY(c, hipMalloc(&c->d_wk_ovf[k], sizeof(double) * wgs * QMPC_ENGINE_OVF_EVENTS * ev));
+  }
   c->wk_cap[k] = (int)cap;
   return QMPC_OK;
 }
@@ -649,6 +661,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       A.wk_hinv = c->d_wk_hinv[sk];
       A.wk_xu = c->d_wk_xu[sk];
       A.wk_hdr = c->d_wk_hdr[sk];
+      A.wk_order = c->d_wk_order[sk];
       A.wk_ld = chain[k] == 2 ? 128 : 192;
       A.wk_cap = c->wk_cap[sk];
       A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
@@ -661,6 +674,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       int nch = c->chunks > 0 ? c->chunks : 1;
       if (nch > QMPC_MAX_CHUNKS) nch = QMPC_MAX_CHUNKS;
       const int per = (batch + nch - 1) / nch;
+      A.wk_ovf = nch > 1 ? nullptr : c->d_wk_ovf[sk];  // (chunks' engine kernels overlap: no shared slices; they hand back instead)
       if (nch > 1) {
         if (const int rc = ensure_aux(c)) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_fork, stream));
@@ -672,6 +686,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         hipStream_t sa = nch > 1 ? c->aux[0] : stream, sb = nch > 1 ? c->aux[1 + (ch & 1)] : stream;
         A.wk_count = cnt + 16 + 8 * sk + ch;
         A.wk_qhead = cnt + 32 + 8 * sk + ch;
+        A.wk_bucket = cnt + 64 + QMPC_ORDER_BUCKETS * (8 * sk + ch);
         A.wk_base = lo;
         A.rid0 = lo;
         A.list_hi = hi;

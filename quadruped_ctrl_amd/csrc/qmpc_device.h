@@ -30,11 +30,15 @@
 //   chunked launches of the decoupled path (sweep / engine kernels of consecutive robot ranges on separate streams, so
 //   that a chunk's active set runs beside the next chunk's sweep), split class sk = 0 (128 rows) / 1 (192 rows), chunk c < 8:
 //   [16 + 8 sk + c] work items produced   [32 + 8 sk + c] engine queue head   [48 + 8 sk + c] sweep kernel's list queue head
-#define QMPC_COUNTERS 64
+//   [64 + 16 (8 sk + c) + b] work items in order bucket b (hardest robots first: the engine workgroups take the items
+//   bucket by bucket -- a launch ends with its slowest robot, which must not be the one that started last)
 #define QMPC_MAX_CHUNKS 8
+#define QMPC_ORDER_BUCKETS 16
+#define QMPC_COUNTERS (64 + 2 * QMPC_MAX_CHUNKS * QMPC_ORDER_BUCKETS)
 
 // decoupled path: a sweep workgroup (or the long-horizon producer) leaves its robot's explicit inverse,
 // unconstrained minimiser and stance list in a work item; single-robot engine workgroups consume the items
+#define QMPC_ENGINE_OVF_EVENTS 96  // events per engine workgroup in the overflow pool (beyond its registers and LDS)
 #define QMPC_WK_SLOTS_MAX 192  // stance slots an item can describe (three 64-lane groups; trot at horizon 36 has 72)
 struct QmpcWorkHdr {
   int rid, n, nst, status0;              // robot, reduced size 3 nst, stance foot-steps, status bits so far
@@ -106,6 +110,11 @@ struct QmpcParams {
   int* wk_qhead;
   int wk_ld, wk_cap;
   int wk_base;  // first work item of this launch's chunk (items wk_base .. wk_base + *wk_count - 1)
+  // order in which the engine workgroups take the items: QMPC_ORDER_BUCKETS lists of item indices, bucket b of this chunk
+  // at wk_order[b * wk_cap + wk_base ...], wk_bucket[b] entries; bucket 0 = most rows violated at x_u
+  int* wk_order;
+  int* wk_bucket;
+  double* wk_ovf;  // engine kernel: overflow event pool, one slice of QMPC_ENGINE_OVF_EVENTS records per workgroup of the grid
   int rid0;     // sweep kernel: first robot (or list entry) of this launch's chunk
   int list_hi;  // ... and one past its last list entry (list-consuming launches)
   int wk_block;  // 1: the engine starts from a block-factorised candidate set (block_start, qmpc_engine.hip)

@@ -43,7 +43,10 @@ struct ECfg {
   static constexpr int RE = RE_, KQ = KQ_, SQ = SQ_, NW = NW_, MAXL = MAXL_, MAXE = MAXE_;
   static constexpr int NH = NW - 1, NP = 64 * RE, KS = 64 * KQ, NSL = 64 * SQ, NT = 64 * NW;
   static constexpr int NRR = (NH + 1) * MAXL;     // events dealt round-robin over engine + holders
-  static constexpr int KEV = NH * MAXL + MAXE;    // capacity
+  static constexpr int KEV = NH * MAXL + MAXE;    // capacity of registers + LDS
+  // ... and beyond that the engine wave keeps events in this workgroup's slice of an overflow pool in global memory
+  // (L2): slower per event, but a robot with an unusually long active-set history continues instead of being handed back
+  static constexpr int MAXG = QMPC_ENGINE_OVF_EVENTS;
   static constexpr int EV = NP + KS;
   static_assert(MAXE >= MAXL && MAXE <= 64, "engine-held events");
   // block start: records it may leave -- what the holders' registers take afterwards (its LDS is the engine wave's pool)
@@ -83,6 +86,7 @@ struct ESmem {
   double xl[C::NP];                      // x, variable-indexed, for the stance-slot lanes of the selection
   double D[C::NP];                       // diag(H^-1)
   float fb[12];
+  signed char gsign[C::MAXG];            // overflow events in global memory: +1 add, -1 drop
   // block start (see block_start): working set and multipliers by slot, the signs of the records in the event pool
   struct Blk {
     int ne, nadd, nc, fail, dl, pad0, pad1, pad2;
@@ -489,9 +493,12 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
   const int h = P.horizon;
   long long* dbg_clk = P.dbg_clk ? P.dbg_clk + (size_t)rid * 16 : nullptr;
   if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
-  const bool blk = P.wk_block != 0;
-  if (blk) block_start<C>(tid, S, Hi, xu, n, nst, P.max_iter);
-  else if (tid == 0) {
+  // (the experimental block start needs one thread per record entry: the 128-row class's engine has them)
+  const bool blk = C::EV <= C::NT && P.wk_block != 0;
+  if constexpr (C::EV <= C::NT) {
+    if (blk) block_start<C>(tid, S, Hi, xu, n, nst, P.max_iter);
+  }
+  if (!blk && tid == 0) {
     S.bk.ne = 0;
     S.bk.fail = 0;
   }
@@ -505,7 +512,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     // =============================================================== the engine wave
     const double mi = P.mu_inv, inv_fr = P.inv_fr_norm, tol = P.tol;
     const int max_iter = __builtin_amdgcn_readfirstlane(P.max_iter);
-    const int kev = __builtin_amdgcn_readfirstlane(P.wk_kev < C::KEV ? P.wk_kev : C::KEV);
+    const int kev = __builtin_amdgcn_readfirstlane(P.wk_kev < C::KEV + C::MAXG ? P.wk_kev : C::KEV + C::MAXG);  // (test hook)
     auto uni = [](bool cnd) __attribute__((always_inline)) { return __builtin_amdgcn_ballot_w64(cnd) != 0ull; };
     double xv[RE];  // (x_u, or the block start's minimiser on its working set)
 #pragma unroll
@@ -526,6 +533,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     }
     int khw = 0, status = 0, nev = 0, iters = 0;
     int nle = 0;                        // events in the engine wave's own LDS pool
+    int ngl = 0;                        // ... and in its slice of the overflow pool in global memory
+    GlobalF64* const gov = P.wk_ovf ? (GlobalF64*)P.wk_ovf + (size_t)blockIdx.x * ((size_t)C::MAXG * EV) : nullptr;
     unsigned long long dropme = 0ull;   // ... that are drop events
     int cnt[NH + 1];                    // events held by owner o (0 = this wave's pool = nle)
 #pragma unroll
@@ -599,6 +608,37 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
           for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gl[u][k], rs[k]);
         }
       }
+      if (ngl > 0) {
+        // overflow events (this wave wrote them, lanes read each other's entries: stores drained, then through L1 / L2)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
+        for (int t0 = 0; t0 < ngl; t0 += 4) {
+          double ya[4], yb[4], zl[4][RE], gl[4][KQ];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const GlobalF64* ev = gov + (size_t)((t0 + u < ngl) ? t0 + u : 0) * EV;
+            ya[u] = ACC ? ev[pj1] : ev[NP + l];
+            yb[u] = ACC ? ev[pj2] : 0.0;
+#pragma unroll
+            for (int q = 0; q < RE; ++q) zl[u][q] = ev[lane + 64 * q];
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) gl[u][k] = ev[NP + lane + 64 * k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool isdrop = S.gsign[(t0 + u < ngl) ? t0 + u : 0] < 0;
+            double y = ACC ? __builtin_fma(pa2, yb[u], pa1 * ya[u]) : ya[u];
+            if (!(t0 + u < ngl)) y = 0.0;
+            const double yz = ACC ? (isdrop ? y : -y) : y;
+            const double yr = ACC ? y : (isdrop ? -y : y);
+#pragma unroll
+            for (int q = 0; q < RE; ++q) zs[q] = __builtin_fma(yz, zl[u][q], zs[q]);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gl[u][k], rs[k]);
+          }
+        }
+      }
     };
     // one round with the holders: the request goes up, (A), everybody accumulates over the events it holds, (B), the
     // partial sums come back and are added in a fixed order.  `pre` runs between the barriers
@@ -626,6 +666,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       bool room = false;
 #pragma unroll
       for (int o = 0; o <= NH; ++o) room |= cnt[o] < ((o == 0) ? MAXE : MAXL);
+      room |= gov != nullptr && ngl < C::MAXG;
       return room && nev < kev;
     };
     auto place_event = [&](const double (&zv)[RE], const double (&gv)[KQ], bool is_drop, int clear_slot) __attribute__((always_inline)) {
@@ -643,17 +684,31 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
 #pragma unroll
       for (int o = 0; o <= NH; ++o)
         if (o == owner) cnt[o] += 1;
-      double* const dst = (owner == 0) ? S.epool[li] : S.stage;
-#pragma unroll
-      for (int q = 0; q < RE; ++q) dst[lane + 64 * q] = zv[q];
-#pragma unroll
-      for (int k = 0; k < KQ; ++k) dst[NP + lane + 64 * k] = gv[k];
-      if (clear_slot >= 0 && lane < nle) S.epool[lane][NP + clear_slot] = 0.0;
-      if (owner == 0) {
-        if (is_drop) dropme |= (1ull << li);
-        nle = li + 1;
+      if (clear_slot >= 0) {
+        if (lane < nle) S.epool[lane][NP + clear_slot] = 0.0;
+        for (int e = lane; e < ngl; e += 64) gov[(size_t)e * EV + NP + clear_slot] = 0.0;
       }
-      if (lane == 0 && (owner != 0 || clear_slot >= 0))
+      if (owner < 0) {
+        // registers and LDS are full: the event goes to the overflow pool
+        GlobalF64* const dst = gov + (size_t)ngl * EV;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) dst[lane + 64 * q] = zv[q];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) dst[NP + lane + 64 * k] = gv[k];
+        if (lane == 0) S.gsign[ngl] = is_drop ? -1 : 1;
+        ngl += 1;
+      } else {
+        double* const dst = (owner == 0) ? S.epool[li] : S.stage;
+#pragma unroll
+        for (int q = 0; q < RE; ++q) dst[lane + 64 * q] = zv[q];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) dst[NP + lane + 64 * k] = gv[k];
+        if (owner == 0) {
+          if (is_drop) dropme |= (1ull << li);
+          nle = li + 1;
+        }
+      }
+      if (lane == 0 && (owner > 0 || clear_slot >= 0))
         *reinterpret_cast<int4*>(&S.rq.ing_valid) = int4{1, owner, li, (is_drop ? 1 : 0) | ((clear_slot + 1) << 8)};
       nev += 1;
     };
@@ -783,6 +838,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       khw = __builtin_amdgcn_readfirstlane(khw);
       nev = __builtin_amdgcn_readfirstlane(nev);
       nle = __builtin_amdgcn_readfirstlane(nle);
+      ngl = __builtin_amdgcn_readfirstlane(ngl);
 #pragma unroll
       for (int o = 0; o <= NH; ++o) cnt[o] = __builtin_amdgcn_readfirstlane(cnt[o]);
       status = __builtin_amdgcn_readfirstlane(status);
@@ -1128,16 +1184,30 @@ __global__ __launch_bounds__(64 * NW, 2) void qmpc_engine_kernel(const QmpcParam
   static_assert(sizeof(QmpcParams) % 4 == 0 && sizeof(QmpcParams) / 4 <= 64 * NW, "parameter block copy");
   if (threadIdx.x < sizeof(QmpcParams) / 4)
     reinterpret_cast<uint32_t*>(&S.par)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P)[threadIdx.x];
+  // queue position -> work item: the sweep kernel filed the items in QMPC_ORDER_BUCKETS lists, hardest robots first
+  // (complete: this kernel starts after the sweep kernel of its chunk has finished)
+  auto item_at = [&](int pos) __attribute__((always_inline)) {
+    int b = 0, cb = P.wk_bucket[0];
+    while (b + 1 < QMPC_ORDER_BUCKETS && pos >= cb) {
+      pos -= cb;
+      cb = P.wk_bucket[++b];
+    }
+    return P.wk_order[(size_t)b * P.wk_cap + P.wk_base + pos];
+  };
+  if (threadIdx.x == 0) S.qnext = item_at((int)blockIdx.x);
   __syncthreads();
-  for (int idx = (int)blockIdx.x;;) {
+  for (;;) {
+    const int item = S.qnext;
     int tid1 = (int)threadIdx.x;
     asm volatile("" : "+v"(tid1));
     __builtin_assume(tid1 >= 0 && tid1 < 64 * NW);
-    engine_item<C, false>(P.wk_base + idx, tid1, S, P);
-    if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.wk_qhead, 1);
+    engine_item<C, false>(item, tid1, S, P);  // (ends with a workgroup barrier)
+    if (threadIdx.x == 0) {
+      const int pos = (int)gridDim.x + atomicAdd(P.wk_qhead, 1);
+      S.qnext = pos < nitems ? item_at(pos) : -1;
+    }
     __syncthreads();
-    idx = S.qnext;
-    if (idx >= nitems) break;  // uniform
+    if (S.qnext < 0) break;  // uniform
   }
 }
 
@@ -1169,8 +1239,12 @@ struct EngineEntry {
 // 256 VGPRs per lane at two waves per SIMD, ~100 of them for everything else)
 typedef EngineEntry<2, 1, 1, 4, 23, 42> Engine2;
 // engine of the 192-row class: 3 row blocks, 128 working slots (all four feet down at horizon 14 / 16 ends with 70-90 rows at
-// a bound when braking): 10 VGPRs per event, 7 holders x 15 + 24 in LDS
-typedef EngineEntry<3, 2, 1, 8, 13, 48> Engine3;
+// a bound when braking): 10 VGPRs per event.  Four waves and 79 KB of LDS -- TWO workgroups per CU (the class's engine
+// phase is bound by the number of robots in flight, not by the slowest robot): 3 holders x 13 events + 25 in LDS, the
+// rest of an unusually long history in the overflow pool
+typedef EngineEntry<3, 2, 1, 4, 13, 25> Engine3;
+static_assert(sizeof(ESmem<Engine3::C>) <= 80 * 1024 && sizeof(ESmem<Engine2::C>) <= 80 * 1024, "two engine workgroups per CU");
+
 }  // namespace
 
 extern "C" hipError_t qmpc_engine_prepare(void) {

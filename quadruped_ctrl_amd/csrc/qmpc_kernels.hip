@@ -1104,6 +1104,31 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       hd->nst = nst;
       hd->status0 = S.status;
     }
+    if (tid < WAVE) {
+      // how hard this robot is going to be: rows violated at x_u (nearly all of them end up in the working set, and
+      // every one costs an iteration).  The engine workgroups take the hardest robots first -- a launch ends with its
+      // slowest robot, and that one must not be the one that started last
+      int viol = 0;
+      if (tid < nst) {
+        double xs[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          const int j = 3 * tid + ax;
+          xs[ax] = Sw.part[0][j] + Sw.part[1][j] + Sw.part[2][j] + Sw.part[3][j];
+        }
+        const double fx = P.mu_inv * xs[0], fy = P.mu_inv * xs[1], nt = -P.tol, ifr = P.inv_fr_norm;
+        viol = ((fx + xs[2]) * ifr < nt) + ((xs[2] - fx) * ifr < nt) + ((fy + xs[2]) * ifr < nt) + ((xs[2] - fy) * ifr < nt) +
+               (S.fmaxk[tid] - xs[2] < nt);
+      }
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) viol += __shfl_xor(viol, sft);
+      if (tid == 0) {
+        const int lvl = viol >> (RB == 2 ? 2 : 3);
+        const int b = QMPC_ORDER_BUCKETS - 1 - (lvl < QMPC_ORDER_BUCKETS - 1 ? lvl : QMPC_ORDER_BUCKETS - 1);
+        const int pos = atomicAdd(P.wk_bucket + b, 1);
+        P.wk_order[(size_t)b * P.wk_cap + P.wk_base + pos] = item;
+      }
+    }
     QMPC_TICK(5);
     __syncthreads();  // (the next robot of a list-consuming workgroup reuses the LDS)
     return false;
@@ -2529,7 +2554,8 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   if constexpr (!LISTED) {
     // (block index first: only block 0 waits for the kernel argument)
-    if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;  // 3 counters + 3 heads
+    if (blockIdx.x == 0 && P.clear_counts)
+      for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;  // 3 counters + 3 heads
     pool_acquire<RB>(S, P);
     solve_robot<RB, CMD, WARM>((int)blockIdx.x, (int)threadIdx.x, S, P);
     pool_release<RB>(S, P);
@@ -2575,7 +2601,8 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_admm_ker
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   if constexpr (!LISTED) {
-    if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && P.clear_counts)
+      for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;
     solve_one<RB, false, false, true>((int)blockIdx.x, (int)threadIdx.x, S, P);
   } else {  // list = queue, as in qmpc_solve_kernel
     const int nlist = *P.count;
@@ -2603,7 +2630,8 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES_A) void qmpc_sweep_
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
   // (a launch covers one CHUNK of the class: robots / list entries rid0 .. ; the chunks of a call run on separate streams)
   if constexpr (!LISTED) {
-    if (blockIdx.x == 0 && threadIdx.x < QMPC_COUNTERS && P.clear_counts) P.clear_counts[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && P.clear_counts)
+      for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;
     solve_one<RB, true, CMD, false, false, true>(P.rid0 + (int)blockIdx.x, (int)threadIdx.x, S, P);
   } else {
     int nlist = *P.count;
