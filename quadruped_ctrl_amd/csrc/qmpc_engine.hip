@@ -273,7 +273,11 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
       const int slot = id / 5, ty = id - 5 * slot, j0 = 3 * slot;
       const int j1 = (ty < 4) ? j0 + (ty >> 1) : j0 + 2, j2 = j0 + 2;
       const double a1 = (ty < 4) ? ((ty & 1) ? -mi : mi) : -1.0, a2 = (ty < 4) ? 1.0 : 0.0;
-      zc[ci] = (isvar && tid < n) ? __builtin_fma(a2, Hi[(size_t)j2 * LD + tid], a1 * Hi[(size_t)j1 * LD + tid]) : 0.0;
+      // (lower block triangle: above the column's diagonal block by symmetry from the row, below it from the column)
+      const bool up1 = (tid >> 6) <= (j1 >> 6), up2 = (tid >> 6) <= (j2 >> 6);
+      zc[ci] = (isvar && tid < n) ? __builtin_fma(a2, up2 ? Hi[(size_t)j2 * LD + tid] : Hi[(size_t)tid * LD + j2],
+                                                  a1 * (up1 ? Hi[(size_t)j1 * LD + tid] : Hi[(size_t)tid * LD + j1]))
+                                  : 0.0;
     });
 #pragma unroll 1
     for (int ci = 0; ci < nc && !stop; ++ci) {
@@ -484,9 +488,12 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     S.fmaxk[k] = hd->fmaxk[k < QMPC_WK_SLOTS_MAX ? k : 0];
     S.sidx[k] = hd->sidx[k < QMPC_WK_SLOTS_MAX ? k : 0];
   }
-  for (int k = tid; k < NP; k += C::NT) {
-    S.D[k] = Hi[(size_t)k * LD + k];
-    S.xl[k] = xu[k];
+  {
+    const int n0 = hd->n;  // (rows and columns past n are not part of the item)
+    for (int k = tid; k < NP; k += C::NT) {
+      S.D[k] = (k < n0) ? Hi[(size_t)k * LD + k] : 1.0;
+      S.xl[k] = xu[k];
+    }
   }
   __syncthreads();
   const int n = S.n, nst = S.nst, rid = S.rid;
@@ -801,10 +808,15 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       lp = 0.0;
       // in flight across barrier (A) (which only orders LDS) and the accumulation over the events, and -- from the second
       // iteration on -- across the placement of the previous event; consumed right before (B)
+      // (the work item holds the lower block triangle of H^-1: the 64-row blocks up to the column's own come from ROW
+      //  pj -- symmetry, coalesced --, the blocks below it from the column itself, one row stride per lane)
+      const int qb = pj1 >> 6;  // (pj1 and pj2 belong to the same stance slot; a slot may straddle two blocks)
+      const int qb2 = pj2 >> 6;
 #pragma unroll
       for (int q = 0; q < RE; ++q) {
-        c1[q] = Hi[(size_t)pj1 * LD + lane + 64 * q];
-        c2[q] = Hi[(size_t)pj2 * LD + lane + 64 * q];
+        const int row = lane + 64 * q;
+        c1[q] = (row < n) ? ((q <= qb) ? Hi[(size_t)pj1 * LD + row] : Hi[(size_t)row * LD + pj1]) : 0.0;
+        c2[q] = (row < n) ? ((q <= qb2) ? Hi[(size_t)pj2 * LD + row] : Hi[(size_t)row * LD + pj2]) : 0.0;
       }
       return true;
     };

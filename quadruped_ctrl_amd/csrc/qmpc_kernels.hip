@@ -495,6 +495,10 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       const double t = (double)(ek + 1) * PK.dt;
       double val;
       if (row < 3) {
+        // (float products and sums evaluated one by one, like the reference's x86 build: whether the compiler fuses them
+        //  otherwise depends on the shape of the surrounding code, and two instantiations of this template can disagree
+        //  in the last float bit of the angles -- 2e-8 in g)
+#pragma clang fp contract(off)
         // x0(0..2) = roll, pitch, yaw from the quaternion (SolverMPC.cpp:257-267, :318)
         const float w = g_q[0], x = g_q[1], y = g_q[2], z = g_q[3];
         // roll and yaw share ONE atan2f evaluation (the rows diverge inside a wave, so two
@@ -767,7 +771,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
         }
       }
-      if (drag) {  // uniform
+      // (uniform, and rare.  The 128- / 192-row classes are short of registers in this stage: marked cold, the block is laid out
+      //  of line and its spills stay inside it; the smaller classes allocate better without the hint)
+      if ((RB == 2 || RB == 3) ? __builtin_expect(drag, false) : drag) {
         // E_01 / E_12 couple (z of foot-step i, x of foot-step j); E_10 / E_21 the
         // transposed pair (C_qp[i][j] == C_pq[j][i]); E_22 couples x with x.
         const double w11 = Aa.W[11] * dm2, w5 = Aa.W[5] * dm2, w5x = Aa.W[5] * (x_drag * dm2);
@@ -1088,9 +1094,22 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     // two or three coalesced loads.
     const int item = S.evslot;
     constexpr int LD = NP;
+    // Only the LOWER BLOCK TRIANGLE (64-row blocks; the diagonal blocks in full) of the first n rows and columns is
+    // written: the engine takes the part of a column that lies above the diagonal block from the row (symmetry) and
+    // the part below it with strided loads.  All CUs dump at the same time; what does not fit the L2 (4 MB per XCD, 32
+    // CUs) drains at the XCD's write bandwidth while every wave of the chip waits in its stores (46 k of 248 k cycles
+    // per robot with full 192 x 192 matrices, 9.2 MB per XCD and round) -- 152 KB instead of 288 KB per robot at n = 168,
+    // 87 instead of 128 KB at n = 120.  (A wave is one 64-row block and one column group: the bound is wave-uniform.)
     GlobalF64* const Hrow = (GlobalF64*)P.wk_hinv + (size_t)item * (LD * LD) + (size_t)i * LD + c * CW;
+    {
+      const int nev = (n + 1) & ~1;  // (16-byte stores)
+      int cend = 64 * (i / 64 + 1);
+      cend = cend < nev ? cend : nev;
+      const int cnt = (i < n) ? cend - c * CW : 0;  // columns of this thread's group to write
 #pragma unroll
-    for (int jj = 0; jj < CW; jj += 2) st2(Hrow + jj, -a[jj], -a[jj + 1]);
+      for (int jj = 0; jj < CW; jj += 2)
+        if (jj < cnt) st2(Hrow + jj, -a[jj], -a[jj + 1]);
+    }
     if (tid < NP)
       P.wk_xu[(size_t)item * LD + tid] = (tid < n) ? Sw.part[0][tid] + Sw.part[1][tid] + Sw.part[2][tid] + Sw.part[3][tid] : 0.0;
     QmpcWorkHdr* const hd = P.wk_hdr + item;

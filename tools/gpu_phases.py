@@ -17,6 +17,12 @@ clk = mpc.debug_clock(B)
 mpc.solve_async(B, inp, out); torch.cuda.synchronize()
 c = clk.cpu().numpy().astype(np.float64)
 it = o["iters"].cpu().numpy()
+if os.environ.get("QMPC_PHASE_SWEEP_ONLY"):
+    # decoupled path: the engine kernel stamps the same rows from iteration 20 on; keep the robots it left alone
+    # (phases 0..4 are the sweep kernel's; 5 and 6 are meaningless here)
+    keep = it < 20
+    c, it = c[keep], it[keep]
+    print(f"(sweep kernel's stamps of the {keep.sum()} robots with fewer than 20 iterations)")
 names = ["0 inputs", "1 E/s", "2 asm H,g", "3 sweep", "4 x_u", "5 active set", "6 out"]
 d = np.diff(c[:, :8], axis=1)
 print(f"cfg{cfg} B={B}: per-phase shader cycles (median / mean / max over blocks); iters mean {it.mean():.2f}")
