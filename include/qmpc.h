@@ -77,7 +77,8 @@ extern "C" {
                                 constraints that had entered and left the working set again, and
                                 rebuilt its records from the current working set (no second solve) */
 #define QMPC_ST_SPILLED 128  /* informational, NOT an error: the fast engine's on-chip pool was full and the
-                                robot continued on a slice of the handle's overflow pool in global memory */
+                                robot continued on a slice of the handle's overflow pool in global memory (the
+                                decoupled path's engine: on its workgroup's slice of that kernel's own pool) */
 #define QMPC_ST_ERROR_MASK (15 | 32)
 
 typedef struct qmpc_ctx* qmpc_handle;
@@ -182,11 +183,14 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 
 /* Decoupled path of the 128- and 192-row size classes (n_r > 96: all four feet down, dense random contact tables).
  * on (default): the robot's condensed Hessian is inverted by a sweep kernel that leaves the inverse in a work item
- * in global memory (128 / 288 KiB per robot of the largest batch, allocated when a call first reaches the class or
- * by qmpc_reserve), and the active set is run by a second kernel, one robot per small workgroup with the rank-1
- * events of the method in the register file of helper waves -- instead of one workgroup pinning a whole CU for the
- * whole solve.  Same unique minimiser; a robot that outgrows the engine's registers is re-solved by the
- * one-kernel path.  mode 1 (default): used by handles created for at least 384 robots (128-row class) / 128 robots
+ * in global memory (128 / 288 KiB per robot of the largest batch, of which the lower block triangle is written;
+ * allocated when a call first reaches the class or by qmpc_reserve), and the active set is run by a second kernel,
+ * one robot per small workgroup -- the robots with the most rows violated at the unconstrained minimiser first --
+ * with the rank-1 events of the method in the register file of helper waves, instead of one workgroup pinning a whole
+ * CU for the whole solve.  Same unique minimiser.  A robot whose history outgrows the engine's registers and LDS
+ * continues with the excess in an overflow pool in global memory (QMPC_ST_SPILLED, informational; 96 events per engine
+ * workgroup); one that outgrows that as well, or the engine's working-set slots, is re-solved by the one-kernel path
+ * (QMPC_ST_FALLBACK).  mode 1 (default): used by handles created for at least 384 robots (128-row class) / 128 robots
  * (192-row class) -- smaller batches are latency-bound and the one-kernel path has one launch less on the critical
  * path; it is the handle's max_batch that decides, never the size of a call, so that a robot's result does not depend
  * on the batch it is solved in (the two paths agree to ~1e-14 relative, not bit for bit); mode 2:

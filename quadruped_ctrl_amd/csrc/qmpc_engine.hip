@@ -704,6 +704,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
         for (int k = 0; k < KQ; ++k) dst[NP + lane + 64 * k] = gv[k];
         if (lane == 0) S.gsign[ngl] = is_drop ? -1 : 1;
         ngl += 1;
+        status |= QMPC_DEV_ST_SPILLED;  // informational
       } else {
         double* const dst = (owner == 0) ? S.epool[li] : S.stage;
 #pragma unroll

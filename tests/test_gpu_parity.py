@@ -969,6 +969,29 @@ def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
     assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
 
 
+def test_decoupled_engine_overflow_events_continue_in_global_memory(mpc_factory):
+    """The 192-row class's engine kernel holds 64 rank-1 events per robot on chip (3 holder waves x 13 in registers,
+    25 in LDS: four waves, two workgroups per CU); a robot with a longer history keeps the excess in its workgroup's
+    slice of an overflow pool in global memory and goes on (status bit 128, informational) -- it is not handed back.
+    All feet down at horizon 16, braking: the hardest robots take 70+ iterations.  Checked against the reference's
+    qpOASES on the same QP and against the one-kernel path."""
+    b = W.make_standing(512, 16)
+    m = mpc_factory(b)
+    m.set_min_stance(64)
+    m.set_split(True)
+    pick = lambda r: np.argsort(r["iters"])[-4:]
+    res, idx, worst, nact = _solver_parity_on_own_qp(m, b, pick)
+    spilled = (res["status"] & 128) != 0
+    print("iters of the hardest", res["iters"][idx].tolist(), "spilled", int(spilled.sum()), "handed back",
+          int(((res["status"] & 16) != 0).sum()), "worst err vs qpOASES", worst)
+    assert not (res["status"] & 16).any()
+    assert spilled.sum() > 0 and (res["iters"][spilled] > 64).all() and (res["iters"][~spilled] <= 64).all()
+    m.set_split(False)
+    one = m.solve(b, full=True)
+    scale = np.abs(one["soln"]).max(1).clip(1.0)
+    assert (np.abs(res["soln"] - one["soln"]).max(1) / scale).max() < 1e-9
+
+
 def test_class3_working_sets_beyond_ninety_constraints_and_compaction(mpc_factory):
     """All feet down at horizon 16, hard commands, force limit 40 N: up to 158 active-set iterations and working sets
     of 100+ constraints.  The 192-row class's pool slice holds 160 events for its 128 slots (with 96, such robots
