@@ -47,6 +47,7 @@ struct ECfg {
   // ... and beyond that the engine wave keeps events in this workgroup's slice of an overflow pool in global memory
   // (L2): slower per event, but a robot with an unusually long active-set history continues instead of being handed back
   static constexpr int MAXG = QMPC_ENGINE_OVF_EVENTS;
+  static constexpr int BIAS = (RE == 2) ? 5 : 7;  // events the engine wave is dealt fewer than a holder (measured)
   static constexpr int EV = NP + KS;
   static_assert(MAXE >= MAXL && MAXE <= 64, "engine-held events");
   // block start: records it may leave -- what the holders' registers take afterwards (its LDS is the engine wave's pool)
@@ -463,6 +464,14 @@ __device__ __forceinline__ void block_start(const int tid, ESmem<C>& S, const Gl
   __syncthreads();
 }
 
+// +-1.0 in a scalar register pair, opaque to the optimiser (which would turn y * (c ? 1 : -1) back into a negation and a
+// select).  acc: the sign of an event's term in z (-1 add, +1 drop); otherwise its sign in S^-1 (+1 add, -1 drop)
+__device__ __forceinline__ double event_sign(unsigned long long isdrop, bool acc) {
+  unsigned hi = ((isdrop != 0ull) == acc) ? 0x3FF00000u : 0xBFF00000u;
+  asm volatile("" : "+s"(hi));
+  return __longlong_as_double((long long)((unsigned long long)hi << 32));
+}
+
 template <class C, bool WARM>
 __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem<C>& S, const QmpcParams& PK) {
   constexpr int RE = C::RE, KQ = C::KQ, SQ = C::SQ, NH = C::NH, NP = C::NP, KS = C::KS, MAXL = C::MAXL, LD = C::NP;
@@ -648,16 +657,19 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       }
     };
     // one round with the holders: the request goes up, (A), everybody accumulates over the events it holds, (B), the
-    // partial sums come back and are added in a fixed order.  `pre` runs between the barriers
-    auto round = [&](int cmd, int l, double (&zs)[RE], double (&rs)[KQ], auto&& pre) __attribute__((always_inline)) {
+    // partial sums come back and are added in a fixed order.  Between the barriers the engine wave does everything that
+    // does not need the sums: it PLACES THE EVENT OF THE PREVIOUS ROUND (reciprocal square root, scaling, staging it for
+    // its owner -- none of that is on the holders' critical path any more) and adds that event's term itself, from
+    // registers; the holders accumulate over the events they already have and take the staged one after (B)
+    auto post = [&](int cmd, int l) __attribute__((always_inline)) {
       if (lane == 0) {
         *reinterpret_cast<int4*>(&S.rq.cmd) = int4{cmd, pj1, pj2, l};
         st2(&S.rq.pa1, pa1, pa2);
       }
       lds_barrier();  // (A)
-      pre();
+    };
+    auto finish = [&](double (&zs)[RE], double (&rs)[KQ]) __attribute__((always_inline)) {
       lds_barrier();  // (B)
-      if (lane == 0) S.rq.ing_valid = 0;  // (the staged event, if any, has been taken)
 #pragma unroll
       for (int w = 0; w < NH; ++w) {
 #pragma unroll
@@ -676,18 +688,23 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       room |= gov != nullptr && ngl < C::MAXG;
       return room && nev < kev;
     };
-    auto place_event = [&](const double (&zv)[RE], const double (&gv)[KQ], bool is_drop, int clear_slot) __attribute__((always_inline)) {
+    auto place_event = [&](const double (&zv)[RE], const double (&gv)[KQ], bool is_drop, int clear_slot) __attribute__((always_inline)) -> int {
       // the owner with the fewest events that still has room (ties: the lowest index); has_room() was checked before
       int owner = -1, best = 1 << 30;
 #pragma unroll
       for (int o = 0; o <= NH; ++o) {
-        const int cap = (o == 0) ? MAXE : MAXL;
-        if (cnt[o] < cap && cnt[o] < best) {
-          best = cnt[o];
+        // (the engine wave places the events and folds in the columns while the holders accumulate, and its own events
+        //  are in LDS, not in registers: it is dealt BIAS events fewer than a holder)
+        const int cap = (o == 0) ? MAXE : MAXL, load = cnt[o] + (o == 0 ? C::BIAS : 0);
+        if (cnt[o] < cap && load < best) {
+          best = load;
           owner = o;
         }
       }
-      const int li = best;
+      int li = 0;
+#pragma unroll
+      for (int o = 0; o <= NH; ++o)
+        if (o == owner) li = cnt[o];
 #pragma unroll
       for (int o = 0; o <= NH; ++o)
         if (o == owner) cnt[o] += 1;
@@ -716,9 +733,48 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
           nle = li + 1;
         }
       }
-      if (lane == 0 && (owner > 0 || clear_slot >= 0))
-        *reinterpret_cast<int4*>(&S.rq.ing_valid) = int4{1, owner, li, (is_drop ? 1 : 0) | ((clear_slot + 1) << 8)};
+      // (always written: the holders read this word after (B) of every round)
+      if (lane == 0)
+        *reinterpret_cast<int4*>(&S.rq.ing_valid) =
+            int4{(owner > 0 || clear_slot >= 0) ? 1 : 0, owner, li, (is_drop ? 1 : 0) | ((clear_slot + 1) << 8)};
       nev += 1;
+      return owner;
+    };
+    // the event the last working-set change produced, not placed yet: unscaled vectors (z or u; -r or -S^-1[:, l] on the
+    // slots that were in use), the quantity whose inverse square root scales them (delta or gamma), the slot that gets
+    // the scale itself (an add event) or is cleared (a drop event)
+    bool pend = false, pdrop = false;
+    int pone = -1, pzero = -1;
+    double parg = 1.0, pz[RE], pg[KQ];
+#pragma unroll
+    for (int q = 0; q < RE; ++q) pz[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) pg[k] = 0.0;
+    // ... placed in the window of the next round, whatever that round accumulates; when a holder owns it, this wave adds
+    // its term (the holder takes it after (B)); in this wave's own pool (or the overflow pool) own_events covers it
+    auto place_pending = [&](auto accc, int l, double (&zs)[RE], double (&rs)[KQ]) __attribute__((always_inline)) {
+      constexpr bool ACC = decltype(accc)::value;
+      if (!pend) {
+        if (lane == 0) S.rq.ing_valid = 0;
+        return;
+      }
+      const double s = rsqrt_full(parg);
+      double zv[RE], gv[KQ];
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zv[q] = pz[q] * s;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == pone) ? s : ((lane + 64 * k == pzero) ? 0.0 : pg[k] * s);
+      const int owner = place_event(zv, gv, pdrop, pzero);
+      pend = false;
+      if (owner > 0) {
+        double y = ACC ? __builtin_fma(pa2, lane_elem<RE>(zv, pj2), pa1 * lane_elem<RE>(zv, pj1)) : lane_elem<KQ>(gv, l);
+        const double yz = ACC ? (pdrop ? y : -y) : y;
+        const double yr = ACC ? y : (pdrop ? -y : y);
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zs[q] = __builtin_fma(yz, zv[q], zs[q]);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gv[k], rs[k]);
+      }
     };
     __builtin_amdgcn_s_setprio(2);  // the serial part of the workgroup
     // Remove working-set slot l: one drop event.  u = N*_l (variable lanes), sc = S^-1[:, l] (slot lanes) over ALL events (a
@@ -731,7 +787,14 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       for (int q = 0; q < RE; ++q) u[q] = 0.0;
 #pragma unroll
       for (int k = 0; k < KQ; ++k) sc[k] = 0.0;
-      round(CMD_DROPACC, l, u, sc, [&]() __attribute__((always_inline)) { own_events(std::false_type{}, l, u, sc); });
+      if (pend && !has_room()) {
+        retry = true;
+        return false;
+      }
+      post(CMD_DROPACC, l);
+      place_pending(std::false_type{}, l, u, sc);
+      own_events(std::false_type{}, l, u, sc);
+      finish(u, sc);
       const double gamma = lane_elem<KQ>(sc, l);
       if (uni(!(gamma > 0.0))) {
         retry = true;
@@ -747,14 +810,18 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
 #pragma unroll
         for (int k = 0; k < KQ; ++k) lam[k] = __builtin_fma(-coef, sc[k], lam[k]);
       }
-      const double sg = rsqrt_full(gamma);
+      // the drop event (placed in the next round's window): N*_l / sqrt(gamma), -S^-1[:, l] / sqrt(gamma) on the slots in
+      // use, zero in slot l
       const int de = lane_elem<KQ>(wcid, l);
-      double zv[RE], gv[KQ];
 #pragma unroll
-      for (int q = 0; q < RE; ++q) zv[q] = u[q] * sg;
+      for (int q = 0; q < RE; ++q) pz[q] = u[q];
 #pragma unroll
-      for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == l || wcid[k] < 0) ? 0.0 : -sc[k] * sg;
-      place_event(zv, gv, true, l);
+      for (int k = 0; k < KQ; ++k) pg[k] = (wcid[k] < 0) ? 0.0 : -sc[k];
+      parg = gamma;
+      pone = -1;
+      pzero = l;
+      pdrop = true;
+      pend = true;
 #pragma unroll
       for (int k = 0; k < KQ; ++k)
         if (lane + 64 * k == l) {
@@ -832,7 +899,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       }
       const double wmax = wave_max_pos_f64(worst);
       if (!(wmax > 0.0)) break;
-      if (!has_room() || iters >= max_iter) {
+      if (iters >= max_iter) {
         retry = true;
         break;
       }
@@ -852,6 +919,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       nev = __builtin_amdgcn_readfirstlane(nev);
       nle = __builtin_amdgcn_readfirstlane(nle);
       ngl = __builtin_amdgcn_readfirstlane(ngl);
+      pone = __builtin_amdgcn_readfirstlane(pone);
+      pzero = __builtin_amdgcn_readfirstlane(pzero);
 #pragma unroll
       for (int o = 0; o <= NH; ++o) cnt[o] = __builtin_amdgcn_readfirstlane(cnt[o]);
       status = __builtin_amdgcn_readfirstlane(status);
@@ -861,8 +930,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       pj1 = __builtin_amdgcn_readfirstlane(pj1);
       pj2 = __builtin_amdgcn_readfirstlane(pj2);
       QMPC_ESTAMP(0);
-      // ---- room for one more event?  Every pass leaves exactly one (add or drop)
-      if (!has_room()) {
+      // ---- room for the event the previous pass left (it is placed in this round's window)?
+      if (pend && !has_room()) {
         retry = true;
         break;
       }
@@ -874,13 +943,15 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
 #pragma unroll
       for (int q = 0; q < RE; ++q) z[q] = 0.0;
       double d1 = 0.0, d2 = 0.0, xp1 = 0.0, xp2 = 0.0;
-      round(CMD_ACC, 0, z, rw, [&]() __attribute__((always_inline)) {
+      post(CMD_ACC, 0);
+      {
         QMPC_ESTAMP(2);
         // (operands of the step that do not depend on the holders: read while they work)
         d1 = S.D[pj1];
         d2 = S.D[pj2];
         xp1 = S.xl[pj1];
         xp2 = S.xl[pj2];
+        place_pending(std::true_type{}, 0, z, rw);
         own_events(std::true_type{}, 0, z, rw);
 #pragma unroll
         for (int q = 0; q < RE; ++q)
@@ -892,7 +963,8 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
           asm volatile("" ::"v"(zs));
           dbg_clk[3] = clock64();
         }
-      });
+      }
+      finish(z, rw);
       QMPC_ESTAMP(4);
       const double delta = __builtin_fma(pa2, lane_elem<RE>(z, pj2), pa1 * lane_elem<RE>(z, pj1));
       const double cn = __builtin_fma(pa2 * pa2, d2, pa1 * pa1 * d1);  // scale of c_p^T H^-1 c_p
@@ -961,14 +1033,17 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
           retry = true;  // out of working-set slots
           break;
         }
-        // the event's entries need the working set as it was: g~_w = -r_w / sqrt(delta) on the slots in use, 1 / sqrt(delta)
-        // on the new one
-        const double s = rsqrt_full(delta);
-        double zv[RE], gv[KQ];
+        // the add event (placed in the next round's window); its entries need the working set as it was: g~_w = -r_w /
+        // sqrt(delta) on the slots in use, 1 / sqrt(delta) on the new one
 #pragma unroll
-        for (int q = 0; q < RE; ++q) zv[q] = z[q] * s;
+        for (int q = 0; q < RE; ++q) pz[q] = z[q];
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == qslot) ? s : ((wcid[k] >= 0) ? -rw[k] * s : 0.0);
+        for (int k = 0; k < KQ; ++k) pg[k] = (wcid[k] >= 0) ? -rw[k] : 0.0;
+        parg = delta;
+        pone = qslot;
+        pzero = -1;
+        pdrop = false;
+        pend = true;
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
           if (lane + 64 * k == qslot) {
@@ -979,11 +1054,9 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
         for (int s2 = 0; s2 < SQ; ++s2)
           if (lane + 64 * s2 == psl) amask[s2] |= (1u << pty);
         khw = (qslot + 1 > khw) ? qslot + 1 : khw;
-        // the NEXT constraint is chosen, and the loads of its columns issued, BEFORE the event of this one is placed:
-        // the L2 / Infinity-Cache latency of those loads (the inverse was written by another kernel, every column is a
-        // first touch) overlaps the placement, the request and the holders' accumulation
+        // the NEXT constraint is chosen and the loads of its columns issued; its request goes up at once (next pass), and
+        // this event is placed while the holders accumulate
         have_p = select_next();
-        place_event(zv, gv, false, -1);
       } else {
         // ---- partial step: the multiplier of slot l reached zero -> drop it.  p stays (its columns are still in c1, c2)
         if (!drop_slot(l, false)) break;
@@ -1081,52 +1154,13 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       const bool hst = dbg_clk && wv == 1 && lane == 0 && hround == QMPC_EDBG_ITER;  // (rounds ~ iterations while nothing is dropped)
       hround += 1;
       if (hst) dbg_clk[8] = clock64();
-      // the whole request with three broadcast loads in flight together (one LDS round trip, not one per field)
+      // the request: two broadcast loads in flight together (one LDS round trip, not one per field)
       int4 r0 = *reinterpret_cast<const int4*>(&S.rq.cmd);
       F64x2 r1 = ld2(&S.rq.pa1);
-      int4 r2 = *reinterpret_cast<const int4*>(&S.rq.ing_valid);
-      // ... and the staged event with them, whoever it is for (no second round trip for its owner)
-      double zin[RE], gin[KQ];
-#pragma unroll
-      for (int q = 0; q < RE; ++q) zin[q] = S.stage[lane + 64 * q];
-#pragma unroll
-      for (int k = 0; k < KQ; ++k) gin[k] = S.stage[NP + lane + 64 * k];
-      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z),
-                   "+v"(r2.w), "+v"(zin[0]), "+v"(gin[0]));
+      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y));
       const int cmd = __builtin_amdgcn_readfirstlane(r0.x);
       if (cmd == CMD_DONE) break;
       nloc = __builtin_amdgcn_readfirstlane(nloc);
-      // ---- the event the engine staged in the previous round (if any): a dropped working-set slot's column of every
-      // g~ is cleared; the owner takes the record into its registers
-      if (__builtin_amdgcn_readfirstlane(r2.x) != 0) {
-        const int flags = __builtin_amdgcn_readfirstlane(r2.w);
-        const int clr = (flags >> 8) - 1;
-        if (clr >= 0) {
-          const int ck = clr >> 6, cl = clr & 63;
-          Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
-            constexpr int li = decltype(lic)::value;
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) gt[li][k] = (k == ck && lane == cl) ? 0.0 : gt[li][k];
-          });
-        }
-        if (__builtin_amdgcn_readfirstlane(r2.y) == wv) {
-          const int myli = __builtin_amdgcn_readfirstlane(r2.z);
-          StaticFor<0, MAXL>::run([&](auto lic) __attribute__((always_inline)) {
-            constexpr int li = decltype(lic)::value;
-            if (li == myli) {
-#pragma unroll
-              for (int q = 0; q < RE; ++q) zt[li][q] = zin[q];
-#pragma unroll
-              for (int k = 0; k < KQ; ++k) gt[li][k] = gin[k];
-              // (a different instruction at the END of every case: the compiler otherwise sinks the stores of all cases
-              //  into one store through a pointer chosen at run time, and the whole register array becomes scratch)
-              asm volatile("; event registers %0" ::"n"(li));
-            }
-          });
-          if (flags & 1) dropm |= (1ull << myli);
-          nloc = myli + 1;
-        }
-      }
       if (hst) dbg_clk[9] = clock64();
       double zp[RE], rp[KQ];
 #pragma unroll
@@ -1137,14 +1171,19 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
         // z -= +-y z~ , r += y g~ with y = z~^T c_p = a1 z~[j1] + a2 z~[j2] over this holder's events; the two entries of
         // z~ come by readlane from registers whose 64-row block is a compile-time constant of the specialised loop
         const int hj1 = __builtin_amdgcn_readfirstlane(r0.y), hj2 = __builtin_amdgcn_readfirstlane(r0.z);
-        const double ha1 = readlane_f64(r1.x, 0), ha2 = readlane_f64(r1.y, 0);
+        // (the coefficients stay in VECTOR registers -- the entries of z~ arrive in scalar ones, and an instruction takes one
+        //  scalar operand: two would cost a copy each -- and an event's sign is a multiplication by +-1.0 held in a scalar
+        //  pair, not a negate-and-select: 10 vector instructions per event in the 128-row class where there were 17, in the
+        //  loop that bounds the iteration)
+        double ha1 = r1.x, ha2 = r1.y;
+        asm volatile("" : "+v"(ha1), "+v"(ha2));
         const int l1 = hj1 & 63, l2 = hj2 & 63;
         dispatch_blocks<RE>(hj1 >> 6, hj2 >> 6, [&](auto q1c, auto q2c) __attribute__((always_inline)) {
           constexpr int Q1 = decltype(q1c)::value, Q2 = decltype(q2c)::value;
           Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
             constexpr int li = decltype(lic)::value;
             const double y = __builtin_fma(ha2, readlane_f64(zt[li][Q2], l2), ha1 * readlane_f64(zt[li][Q1], l1));
-            const double ys = ((dropm >> li) & 1ull) ? y : -y;
+            const double ys = y * event_sign((dropm >> li) & 1ull, true);
 #pragma unroll
             for (int q = 0; q < RE; ++q) zp[q] = __builtin_fma(ys, zt[li][q], zp[q]);
 #pragma unroll
@@ -1157,7 +1196,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
         Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
           constexpr int li = decltype(lic)::value;
           const double y = lane_elem<KQ>(gt[li], hl);
-          const double ys = ((dropm >> li) & 1ull) ? -y : y;
+          const double ys = y * event_sign((dropm >> li) & 1ull, false);
 #pragma unroll
           for (int q = 0; q < RE; ++q) zp[q] = __builtin_fma(y, zt[li][q], zp[q]);
 #pragma unroll
@@ -1178,6 +1217,47 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       for (int k = 0; k < KQ; ++k) mine[NP + lane + 64 * k] = rp[k];
       if (hst) dbg_clk[11] = clock64();
       lds_barrier();  // (B)
+      // ---- the event the engine placed in this round's window (if any), and the dropped working-set slot whose column
+      // of every g~ is cleared: after the sums are out, off everybody's critical path.  One LDS round trip for the
+      // word and the staged record, whoever it is for
+      {
+        int4 r2 = *reinterpret_cast<const int4*>(&S.rq.ing_valid);
+        double zin[RE], gin[KQ];
+#pragma unroll
+        for (int q = 0; q < RE; ++q) zin[q] = S.stage[lane + 64 * q];
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) gin[k] = S.stage[NP + lane + 64 * k];
+        asm volatile("" : "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w), "+v"(zin[0]), "+v"(gin[0]));
+        if (__builtin_amdgcn_readfirstlane(r2.x) != 0) {
+          const int flags = __builtin_amdgcn_readfirstlane(r2.w);
+          const int clr = (flags >> 8) - 1;
+          if (clr >= 0) {
+            const int ck = clr >> 6, cl = clr & 63;
+            Upto<0, MAXL>::run(nloc, [&](auto lic) __attribute__((always_inline)) {
+              constexpr int li = decltype(lic)::value;
+#pragma unroll
+              for (int k = 0; k < KQ; ++k) gt[li][k] = (k == ck && lane == cl) ? 0.0 : gt[li][k];
+            });
+          }
+          if (__builtin_amdgcn_readfirstlane(r2.y) == wv) {
+            const int myli = __builtin_amdgcn_readfirstlane(r2.z);
+            StaticFor<0, MAXL>::run([&](auto lic) __attribute__((always_inline)) {
+              constexpr int li = decltype(lic)::value;
+              if (li == myli) {
+#pragma unroll
+                for (int q = 0; q < RE; ++q) zt[li][q] = zin[q];
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) gt[li][k] = gin[k];
+                // (a different instruction at the END of every case: the compiler otherwise sinks the stores of all cases
+                //  into one store through a pointer chosen at run time, and the whole register array becomes scratch)
+                asm volatile("; event registers %0" ::"n"(li));
+              }
+            });
+            if (flags & 1) dropm |= (1ull << myli);
+            nloc = myli + 1;
+          }
+        }
+      }
     }
   }
   __syncthreads();  // every wave is done with this item's LDS state

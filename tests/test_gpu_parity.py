@@ -962,7 +962,8 @@ def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
     m.set_debug_engine_events(0)
     assert ((cut["status"] & 47) == 0).all()
     back = (cut["status"] & 16) != 0
-    assert back.sum() > 50 and (base["iters"][back] >= 12).all() and (base["iters"][~back] <= 12).all()
+    # (12 events PLACED: the event of the last working-set change never is -- up to 13 iterations stay)
+    assert back.sum() > 50 and (base["iters"][back] >= 13).all() and (base["iters"][~back] <= 13).all()
     scale = np.abs(base["soln"]).max(1).clip(1.0)
     assert (np.abs(cut["soln"] - base["soln"]).max(1) / scale).max() < 1e-9
     assert np.array_equal(cut["soln"][~back], base["soln"][~back])
@@ -985,7 +986,8 @@ def test_decoupled_engine_overflow_events_continue_in_global_memory(mpc_factory)
     print("iters of the hardest", res["iters"][idx].tolist(), "spilled", int(spilled.sum()), "handed back",
           int(((res["status"] & 16) != 0).sum()), "worst err vs qpOASES", worst)
     assert not (res["status"] & 16).any()
-    assert spilled.sum() > 0 and (res["iters"][spilled] > 64).all() and (res["iters"][~spilled] <= 64).all()
+    # (64 events on chip; the event of the last working-set change is never placed: 65 iterations fit)
+    assert spilled.sum() > 0 and (res["iters"][spilled] > 65).all() and (res["iters"][~spilled] <= 65).all()
     m.set_split(False)
     one = m.solve(b, full=True)
     scale = np.abs(one["soln"]).max(1).clip(1.0)
