@@ -188,7 +188,7 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
  * one robot per small workgroup -- the robots with the most rows violated at the unconstrained minimiser first --
  * with the rank-1 events of the method in the register file of helper waves, instead of one workgroup pinning a whole
  * CU for the whole solve.  Same unique minimiser.  A robot whose history outgrows the engine's registers and LDS
- * continues with the excess in an overflow pool in global memory (QMPC_ST_SPILLED, informational; 96 events per engine
+ * continues with the excess in an overflow pool in global memory (QMPC_ST_SPILLED, informational; 160 events per engine
  * workgroup); one that outgrows that as well, or the engine's working-set slots, is re-solved by the one-kernel path
  * (QMPC_ST_FALLBACK).  mode 1 (default): used by handles created for at least 384 robots (128-row class) / 128 robots
  * (192-row class) -- smaller batches are latency-bound and the one-kernel path has one launch less on the critical

@@ -38,7 +38,7 @@
 
 // decoupled path: a sweep workgroup (or the long-horizon producer) leaves its robot's explicit inverse,
 // unconstrained minimiser and stance list in a work item; single-robot engine workgroups consume the items
-#define QMPC_ENGINE_OVF_EVENTS 96  // events per engine workgroup in the overflow pool (beyond its registers and LDS)
+#define QMPC_ENGINE_OVF_EVENTS 160 // events per engine workgroup in the overflow pool (beyond its registers and LDS)
 #define QMPC_WK_SLOTS_MAX 192  // stance slots an item can describe (three 64-lane groups; trot at horizon 36 has 72)
 struct QmpcWorkHdr {
   int rid, n, nst, status0;              // robot, reduced size 3 nst, stance foot-steps, status bits so far

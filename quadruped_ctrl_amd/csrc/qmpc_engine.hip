@@ -80,6 +80,7 @@ struct ESmem {
     int cmd, pj1, pj2, l;
     double pa1, pa2;
     int ing_valid, ing_owner, ing_li, ing_flags;  // ing_flags: bit 0 = drop event, bits 8.. = 1 + slot to clear
+    int nglv, pad0, pad1, pad2;                   // overflow events (global memory) this round's accumulation covers
   } rq;
   alignas(16) double stage[C::EV];       // the new event (z~[NP], g~[KS])
   alignas(16) double epool[C::MAXE][C::EV];  // the engine wave's own events
@@ -472,6 +473,48 @@ __device__ __forceinline__ double event_sign(unsigned long long isdrop, bool acc
   return __longlong_as_double((long long)((unsigned long long)hi << 32));
 }
 
+// A wave's share of an accumulation over the OVERFLOW events (the workgroup's slice in global memory): events first,
+// first + stride, ... below count, four per trip.  The records were written by the engine wave in earlier rounds (its stores
+// drained before the barrier that published `count`); they are read past the L1 (agent-scope loads: the slice is reused from
+// robot to robot, and an L1 line of this CU may hold an older robot's record).  Same sums and signs as own_events
+template <class C, bool ACC>
+__device__ __forceinline__ void ovf_accumulate(const GlobalF64* const gov, const signed char* const gsign, const int first, const int stride,
+                                               const int count, const int j1, const int j2, const int l, const double a1,
+                                               const double a2, const int lane, double (&zs)[C::RE], double (&rs)[C::KQ]) {
+  constexpr int RE = C::RE, KQ = C::KQ, NP = C::NP, EV = C::EV;
+  auto ld = [](const GlobalF64* p) __attribute__((always_inline)) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+#pragma unroll 1
+  for (int g0 = first; g0 < count; g0 += 4 * stride) {
+    double ya[4], yb[4], zl[4][RE], gl[4][KQ];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + u * stride;
+      const GlobalF64* ev = gov + (size_t)(g < count ? g : first) * EV;
+      ya[u] = ACC ? ld(ev + j1) : ld(ev + NP + l);
+      yb[u] = ACC ? ld(ev + j2) : 0.0;
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zl[u][q] = ld(ev + lane + 64 * q);
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) gl[u][k] = ld(ev + NP + lane + 64 * k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + u * stride;
+      const bool isdrop = gsign[g < count ? g : first] < 0;
+      double y = ACC ? __builtin_fma(a2, yb[u], a1 * ya[u]) : ya[u];
+      if (!(g < count)) y = 0.0;
+      const double yz = ACC ? (isdrop ? y : -y) : y;
+      const double yr = ACC ? y : (isdrop ? -y : y);
+#pragma unroll
+      for (int q = 0; q < RE; ++q) zs[q] = __builtin_fma(yz, zl[u][q], zs[q]);
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gl[u][k], rs[k]);
+    }
+  }
+}
+
 template <class C, bool WARM>
 __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem<C>& S, const QmpcParams& PK) {
   constexpr int RE = C::RE, KQ = C::KQ, SQ = C::SQ, NH = C::NH, NP = C::NP, KS = C::KS, MAXL = C::MAXL, LD = C::NP;
@@ -550,6 +593,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     int khw = 0, status = 0, nev = 0, iters = 0;
     int nle = 0;                        // events in the engine wave's own LDS pool
     int ngl = 0;                        // ... and in its slice of the overflow pool in global memory
+    int nglv = 0;                       // (how many of them the current round's request announced)
     GlobalF64* const gov = P.wk_ovf ? (GlobalF64*)P.wk_ovf + (size_t)blockIdx.x * ((size_t)C::MAXG * EV) : nullptr;
     unsigned long long dropme = 0ull;   // ... that are drop events
     int cnt[NH + 1];                    // events held by owner o (0 = this wave's pool = nle)
@@ -624,37 +668,9 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
           for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gl[u][k], rs[k]);
         }
       }
-      if (ngl > 0) {
-        // overflow events (this wave wrote them, lanes read each other's entries: stores drained, then through L1 / L2)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-        for (int t0 = 0; t0 < ngl; t0 += 4) {
-          double ya[4], yb[4], zl[4][RE], gl[4][KQ];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const GlobalF64* ev = gov + (size_t)((t0 + u < ngl) ? t0 + u : 0) * EV;
-            ya[u] = ACC ? ev[pj1] : ev[NP + l];
-            yb[u] = ACC ? ev[pj2] : 0.0;
-#pragma unroll
-            for (int q = 0; q < RE; ++q) zl[u][q] = ev[lane + 64 * q];
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) gl[u][k] = ev[NP + lane + 64 * k];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool isdrop = S.gsign[(t0 + u < ngl) ? t0 + u : 0] < 0;
-            double y = ACC ? __builtin_fma(pa2, yb[u], pa1 * ya[u]) : ya[u];
-            if (!(t0 + u < ngl)) y = 0.0;
-            const double yz = ACC ? (isdrop ? y : -y) : y;
-            const double yr = ACC ? y : (isdrop ? -y : y);
-#pragma unroll
-            for (int q = 0; q < RE; ++q) zs[q] = __builtin_fma(yz, zl[u][q], zs[q]);
-#pragma unroll
-            for (int k = 0; k < KQ; ++k) rs[k] = __builtin_fma(yr, gl[u][k], rs[k]);
-          }
-        }
-      }
+      // ... and its share of the overflow events that were there when the request went up (every wave takes one in NW)
+      if (nglv > 0)
+        ovf_accumulate<C, ACC>(gov, S.gsign, 0, C::NW, nglv, pj1, pj2, l, pa1, pa2, lane, zs, rs);
     };
     // one round with the holders: the request goes up, (A), everybody accumulates over the events it holds, (B), the
     // partial sums come back and are added in a fixed order.  Between the barriers the engine wave does everything that
@@ -662,9 +678,11 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
     // its owner -- none of that is on the holders' critical path any more) and adds that event's term itself, from
     // registers; the holders accumulate over the events they already have and take the staged one after (B)
     auto post = [&](int cmd, int l) __attribute__((always_inline)) {
+      nglv = ngl;
       if (lane == 0) {
         *reinterpret_cast<int4*>(&S.rq.cmd) = int4{cmd, pj1, pj2, l};
         st2(&S.rq.pa1, pa1, pa2);
+        S.rq.nglv = nglv;
       }
       lds_barrier();  // (A)
     };
@@ -722,6 +740,10 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
         if (lane == 0) S.gsign[ngl] = is_drop ? -1 : 1;
         ngl += 1;
         status |= QMPC_DEV_ST_SPILLED;  // informational
+      }
+      if (ngl > 0 && (owner < 0 || clear_slot >= 0)) {
+        // (the record and the cleared entries are in L2 before the next request announces them to the other waves)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       } else {
         double* const dst = (owner == 0) ? S.epool[li] : S.stage;
 #pragma unroll
@@ -766,7 +788,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       for (int k = 0; k < KQ; ++k) gv[k] = (lane + 64 * k == pone) ? s : ((lane + 64 * k == pzero) ? 0.0 : pg[k] * s);
       const int owner = place_event(zv, gv, pdrop, pzero);
       pend = false;
-      if (owner > 0) {
+      if (owner != 0) {  // (a holder's, or in the overflow pool: announced with the next request)
         double y = ACC ? __builtin_fma(pa2, lane_elem<RE>(zv, pj2), pa1 * lane_elem<RE>(zv, pj1)) : lane_elem<KQ>(gv, l);
         const double yz = ACC ? (pdrop ? y : -y) : y;
         const double yr = ACC ? y : (pdrop ? -y : y);
@@ -1132,6 +1154,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       for (int k = 0; k < KQ; ++k) gt[li][k] = 0.0;
     }
     int nloc = 0, hround = 0;
+    const GlobalF64* const hgov = P.wk_ovf ? (const GlobalF64*)P.wk_ovf + (size_t)blockIdx.x * ((size_t)C::MAXG * EV) : nullptr;
     unsigned long long dropm = 0ull;  // local events that are drop events
     if (bkev > 0) {
       // the block start's records (transposed in LDS: Rt[entry][record]): record e goes to holder 1 + e mod NH,
@@ -1157,10 +1180,12 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
       // the request: two broadcast loads in flight together (one LDS round trip, not one per field)
       int4 r0 = *reinterpret_cast<const int4*>(&S.rq.cmd);
       F64x2 r1 = ld2(&S.rq.pa1);
-      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y));
+      int hng = S.rq.nglv;
+      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(hng));
       const int cmd = __builtin_amdgcn_readfirstlane(r0.x);
       if (cmd == CMD_DONE) break;
       nloc = __builtin_amdgcn_readfirstlane(nloc);
+      hng = __builtin_amdgcn_readfirstlane(hng);  // overflow events this round covers: this wave takes every NW-th
       if (hst) dbg_clk[9] = clock64();
       double zp[RE], rp[KQ];
 #pragma unroll
@@ -1190,6 +1215,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
             for (int k = 0; k < KQ; ++k) rp[k] = __builtin_fma(y, gt[li][k], rp[k]);
           });
         });
+        if (hng > 0) ovf_accumulate<C, true>(hgov, S.gsign, wv, C::NW, hng, hj1, hj2, 0, ha1, ha2, lane, zp, rp);
       } else {
         // u = N*_l = sum z~ g~[l] ,  sc = S^-1[:, l] = sum_add g~ g~[l] - sum_drop g~ g~[l]
         const int hl = __builtin_amdgcn_readfirstlane(r0.w);
@@ -1202,6 +1228,7 @@ __device__ __forceinline__ void engine_item(const int item, const int tid, ESmem
 #pragma unroll
           for (int k = 0; k < KQ; ++k) rp[k] = __builtin_fma(ys, gt[li][k], rp[k]);
         });
+        if (hng > 0) ovf_accumulate<C, false>(hgov, S.gsign, wv, C::NW, hng, 0, 0, hl, 0.0, 0.0, lane, zp, rp);
       }
       if (hst) {
         double zs = 0.0;

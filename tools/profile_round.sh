@@ -35,8 +35,8 @@ python $R/tools/split_check.py 1024 2>/dev/null | grep -v "^{" | grep -v amdgpu 
 python $R/tools/engine_phase.py s10 1024 2>/dev/null | grep -v amdgpu > $OUT/engine_phases.txt
 python $R/tools/engine_phase.py s14 1024 2>/dev/null | grep -v amdgpu >> $OUT/engine_phases.txt
 # (the sweep kernels' stage stamps: robots the engine kernel did not stamp over)
-QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s10 1024 2>/dev/null | grep -v amdgpu | head -8 > $OUT/sweep_phases.txt
-QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s14 1024 2>/dev/null | grep -v amdgpu | head -8 >> $OUT/sweep_phases.txt
+QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s10 1024 2>/dev/null | grep -v amdgpu | head -7 > $OUT/sweep_phases.txt
+QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s14 1024 2>/dev/null | grep -v amdgpu | head -7 >> $OUT/sweep_phases.txt
 python $R/tools/chunk_sweep.py 2>/dev/null | grep -v amdgpu > $OUT/chunk_sweep.txt
 # bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
 for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
