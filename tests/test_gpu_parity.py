@@ -970,6 +970,24 @@ def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
     assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
 
 
+def test_decoupled_path_chunked_launches_same_results(mpc_factory):
+    """qmpc_set_chunks (measured: not faster, default 1) runs the sweep / engine kernels of consecutive robot ranges on
+    auxiliary streams: every chunk has its own item counter, order buckets and queue head, and its engine kernel must not
+    share overflow slices with the neighbour's.  Same robots, same kernels: bit-identical results, whatever the split."""
+    b = W.make_standing(700, 10)
+    m = mpc_factory(b)
+    m.set_split(True)
+    base = m.solve(b, full=True)
+    assert ((base["status"] & 47) == 0).all()
+    for nch in (2, 3, 8):
+        m.set_chunks(nch)
+        res = m.solve(b, full=True)
+        assert np.array_equal(res["status"], base["status"]), nch
+        assert np.array_equal(res["soln"], base["soln"]) and np.array_equal(res["iters"], base["iters"]), nch
+    m.set_chunks(1)
+    assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+
+
 def test_decoupled_engine_overflow_events_continue_in_global_memory(mpc_factory):
     """The 192-row class's engine kernel holds 64 rank-1 events per robot on chip (3 holder waves x 13 in registers,
     25 in LDS: four waves, two workgroups per CU); a robot with a longer history keeps the excess in its workgroup's
