@@ -28,6 +28,13 @@ def hard_commands(B, h, seed):
     return rec
 
 
+def hard_stand(B, h, seed):
+    cmd = W.make_commands(B, horizon=h, seed=seed, stand_fraction=1.0)
+    rec, _, _ = O.pack_commands(cmd, np.float32(0.026))
+    rec.update(dt=0.026, mu=0.4, f_max=40.0)
+    return rec
+
+
 def low_fmax(B, seed):
     b = W.make_config(2, batch=B)
     rng = np.random.default_rng(seed)
@@ -43,6 +50,8 @@ FAMILIES = {
     "standing_h10": lambda: W.make_standing(max(N // 8, 8), 10),
     "hard_commands_h10": lambda: hard_commands(N, 10, 5),
     "hard_commands_h14": lambda: hard_commands(max(N // 4, 8), 14, 6),
+    "hard_commands_h16_stand": lambda: dict(hard_stand(max(N // 4, 8), 16, 11)),
+    "standing_h14": lambda: W.make_standing(max(N // 8, 8), 14),
     "low_fmax": lambda: low_fmax(N, 9),
 }
 
@@ -52,6 +61,8 @@ for name, mk in FAMILIES.items():
     B, h = b["batch"], b["horizon"]
     m = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
     m.setup(b["dt"], h, b["mu"], b["f_max"])
+    if os.environ.get("QMPC_STRESS_SPLIT"):   # the decoupled path for every robot of the 128- / 192-row classes
+        m.set_split(2)
     Hd, gd, ld = m.debug_dump(B)
     res = m.solve(b, full=True)
     m.debug_off()
