@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs index")
-    ap.add_argument("--workload", choices=["config", "standing", "trot", "long-trot", "long-bound"], default="config",
+    ap.add_argument("--workload", choices=["config", "standing", "trot", "long-trot", "long-bound", "long-stand"], default="config",
                     help="'standing' = all four feet down for the whole horizon (the robot's default posture, the "
                          "reference's Standing gait, ConvexMPCLocomotion.cpp:35: n_r = 12 h); 'trot' = trot at --horizon")
     ap.add_argument("--horizon", type=int, default=10, help="for --workload standing / trot (reference: 10, 14, 16)")
@@ -211,9 +211,9 @@ def main():
         wkey = f"config{args.config}"
     else:
         per_gpu = args.batch or 1024
-        if args.workload in ("long-trot", "long-bound"):
+        if args.workload in ("long-trot", "long-bound", "long-stand"):
             # horizons beyond the reference's own gaits, up to K_MAX_GAIT_SEGMENTS = 36 (the 192-row class)
-            full = workloads.make_long_horizon(per_gpu * world, args.horizon, "trot" if args.workload == "long-trot" else "bound")
+            full = workloads.make_long_horizon(per_gpu * world, args.horizon, args.workload[5:])
         else:
             mk = workloads.make_standing if args.workload == "standing" else workloads.make_trot
             full = mk(per_gpu * world, args.horizon)

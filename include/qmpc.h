@@ -279,6 +279,10 @@ int qmpc_set_debug_engine_events(qmpc_handle h, int n);
  * workgroup of that class times out waiting for one: its robots must then be solved by the Schur-form engine
  * (QMPC_ST_FALLBACK set, same answer) instead of proceeding on a slice they do not own. */
 int qmpc_set_debug_pool_busy(qmpc_handle h, int on);
+/* Test hook: copies work item `item` of the decoupled path (which: 0 = 128-row class, 1 = 192-row class, 2 = large problems)
+ * to the host after a solve: the inverse (ld x ld doubles, ld = 128 / 192 / 448; the 128- / 192-row classes write the lower block
+ * triangle only), x_u (ld doubles), {rid, n, nst, status bits} (4 ints).  Any pointer may be NULL. */
+int qmpc_debug_read_item(qmpc_handle h, int which, int item, double* hinv_host, double* xu_host, int* hdr4);
 /* Profiling hook: DEVICE buffer clk[B][16] receiving shader-clock stamps at
  * the kernel's phase boundaries (NULL = off). */
 int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);

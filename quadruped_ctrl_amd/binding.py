@@ -25,7 +25,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
            "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
-           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start"]
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
@@ -100,6 +100,7 @@ def load_library():
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_debug_overflow_slices.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_debug_pool_busy.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_debug_read_item.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_set_split.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_reserve.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_engine_events.argtypes = [C.c_void_p, C.c_int]
@@ -484,6 +485,17 @@ class BatchedConvexMPC:
 
     def reserve(self):
         self._check(self.lib.qmpc_reserve(self.h), "qmpc_reserve")
+
+    def debug_read_item(self, which, item):
+        """Test hook: (H^-1 [ld, ld], x_u [ld], (rid, n, nst, status)) of a work item of the decoupled path after a solve."""
+        ld = (128, 192, 448)[which]
+        hinv = np.zeros((ld, ld), np.float64)
+        xu = np.zeros(ld, np.float64)
+        hdr = np.zeros(4, np.int32)
+        self._check(self.lib.qmpc_debug_read_item(self.h, int(which), int(item), hinv.ctypes.data_as(C.c_void_p),
+                                                  xu.ctypes.data_as(C.c_void_p), hdr.ctypes.data_as(C.c_void_p)),
+                    "qmpc_debug_read_item")
+        return hinv, xu, hdr
 
     def set_debug_pool_busy(self, on):
         self._check(self.lib.qmpc_set_debug_pool_busy(self.h, int(bool(on))), "qmpc_set_debug_pool_busy")

@@ -31,6 +31,8 @@ QMPC_DECLARE_CLASS(4)
 
 // the decoupled path's consumer (qmpc_engine.hip)
 extern "C" hipError_t qmpc_engine_prepare(void);
+extern "C" hipError_t qmpc_big_prepare(void);
+extern "C" hipError_t qmpc_big_launch(const QmpcParams* P, int grid, hipStream_t stream);
 extern "C" int qmpc_engine_resident(int rb);
 extern "C" int qmpc_engine_capacity(int rb);
 extern "C" hipError_t qmpc_engine_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
@@ -59,6 +61,7 @@ static hipError_t qmpc_prepare(void) {
   if ((e = qmpc_c4_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c2_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c3_prepare()) != hipSuccess) return e;
+  if ((e = qmpc_big_prepare()) != hipSuccess) return e;
   return qmpc_engine_prepare();
 }
 static hipError_t qmpc_launch_sweep(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
@@ -100,16 +103,16 @@ struct qmpc_ctx {
   double tol = 1e-9;
   float leg_geom[4] = {0.062f, 0.209f, 0.195f, 0.004f};  // MiniCheetah.h:31-37 (abad, hip, knee, knee Y offset)
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
-  int* d_lists = nullptr;      // [3][max_batch] robot ids handed to classes 4, 2 and 3
+  int* d_lists = nullptr;      // [4][max_batch] robot ids handed to classes 4, 2 and 3, and to the large-problem producer
   int* d_counts = nullptr;     // [2 sets][QMPC_COUNTERS] (layout in qmpc_device.h); ping-ponged between calls
   // decoupled path (sweep kernel -> work items -> engine kernel) of the 128- and 192-row classes: [0] class 2, [1] class 3
   int split = 1;               // qmpc_set_split: 0 off, 1 automatic (by batch size), 2 always; QMPC_NO_SPLIT=1 in the environment: 0 at creation
-  double* d_wk_hinv[2] = {nullptr, nullptr};
-  double* d_wk_xu[2] = {nullptr, nullptr};
-  QmpcWorkHdr* d_wk_hdr[2] = {nullptr, nullptr};
-  int* d_wk_order[2] = {nullptr, nullptr};
-  double* d_wk_ovf[2] = {nullptr, nullptr};  // engine kernels' overflow event pools (one slice per resident workgroup)  // [QMPC_ORDER_BUCKETS][max_batch] item indices, hardest robots first
-  int wk_cap[2] = {0, 0};
+  double* d_wk_hinv[3] = {nullptr, nullptr, nullptr};
+  double* d_wk_xu[3] = {nullptr, nullptr, nullptr};
+  QmpcWorkHdr* d_wk_hdr[3] = {nullptr, nullptr, nullptr};  // [2]: the large problems (192 < n_r <= 432)
+  int* d_wk_order[3] = {nullptr, nullptr, nullptr};
+  double* d_wk_ovf[3] = {nullptr, nullptr, nullptr};  // engine kernels' overflow event pools (one slice per resident workgroup)  // [QMPC_ORDER_BUCKETS][max_batch] item indices, hardest robots first
+  int wk_cap[3] = {0, 0, 0};
   int* d_fb_lists = nullptr;   // [2][max_batch] robots the engine kernels hand back
   // chunked launches of the decoupled path: sweep kernels of consecutive chunks on aux[0], engine kernels alternating
   // on aux[1] / aux[2], so that a chunk's active set runs beside the next chunk's sweep; joined into the caller's stream
@@ -215,7 +218,7 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   DeviceGuard g(device_id);
   const size_t H = (size_t)max_horizon;
   hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
-  if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 3 * (size_t)max_batch);
+  if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 4 * (size_t)max_batch);  // ([3]: the large problems, horizons > 16)
   if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 2 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 2 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 2 * (size_t)max_batch);
@@ -259,7 +262,7 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     for (int k = 0; k < QMPC_MAX_CHUNKS; ++k)
       if (h->ev_chunk[k]) hipEventDestroy(h->ev_chunk[k]);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
       if (h->d_wk_hdr[k]) hipFree(h->d_wk_hdr[k]);
@@ -469,6 +472,19 @@ int qmpc_set_debug_aux(qmpc_handle c, double* aux_dev) {
 
 int qmpc_debug_ld(qmpc_handle) { return QMPC_DBG_LD; }
 
+// test hook: a work item of the decoupled path after a solve -- which: 0 = 128-row class, 1 = 192-row class, 2 = large
+// problems; hinv_host: ld x ld doubles (ld = 128 / 192 / 448), xu_host: ld doubles, hdr4: {rid, n, nst, status0}
+int qmpc_debug_read_item(qmpc_handle c, int which, int item, double* hinv_host, double* xu_host, int* hdr4) {
+  if (!c || which < 0 || which > 2 || !c->d_wk_hinv[which] || item < 0 || item >= c->wk_cap[which]) return QMPC_ERR_ARG;
+  DeviceGuard g(c->device);
+  const size_t ld = which == 0 ? 128 : (which == 1 ? 192 : QMPC_BIG_LD);
+  HIP_TRY(c, hipDeviceSynchronize());
+  if (hinv_host) HIP_TRY(c, hipMemcpy(hinv_host, c->d_wk_hinv[which] + (size_t)item * ld * ld, sizeof(double) * ld * ld, hipMemcpyDeviceToHost));
+  if (xu_host) HIP_TRY(c, hipMemcpy(xu_host, c->d_wk_xu[which] + (size_t)item * ld, sizeof(double) * ld, hipMemcpyDeviceToHost));
+  if (hdr4) HIP_TRY(c, hipMemcpy(hdr4, c->d_wk_hdr[which] + item, sizeof(int) * 4, hipMemcpyDeviceToHost));
+  return QMPC_OK;
+}
+
 int qmpc_set_debug_clock(qmpc_handle c, long long* clk_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_clk = clk_dev;
@@ -488,10 +504,10 @@ bool command_ok(const qmpc_command* cmd) {
 
 // work items of the decoupled path for size class rb (2 or 3): one per robot of the largest batch (the inverse is
 // 128 / 288 KiB per robot).  Allocated on the first call that can reach the class (qmpc_reserve does it up front)
-int ensure_split(qmpc_ctx* c, int rb) {
-  const int k = rb == 2 ? 0 : 1;
+int ensure_split(qmpc_ctx* c, int rb) {  // (rb 5: the large problems, 448-row items)
+  const int k = rb == 2 ? 0 : (rb == 3 ? 1 : 2);
   if (c->d_wk_hinv[k]) return QMPC_OK;
-  const size_t ld = rb == 2 ? 128 : 192, cap = (size_t)c->max_batch;
+  const size_t ld = rb == 2 ? 128 : (rb == 3 ? 192 : QMPC_BIG_LD), cap = (size_t)c->max_batch;
   HIP_TRY(c, hipMalloc(&c->d_wk_hinv[k], sizeof(double) * cap * ld * ld));
   HIP_TRY(c, hipMalloc(&c->d_wk_xu[k], sizeof(double) * cap * ld));
   HIP_TRY(c, hipMalloc(&c->d_wk_hdr[k], sizeof(QmpcWorkHdr) * cap));
@@ -500,7 +516,7 @@ int ensure_split(qmpc_ctx* c, int rb) {
     // (the engine grid never exceeds the resident workgroups: slice = blockIdx.x)
     size_t wgs = (size_t)qmpc_engine_resident(rb);
     if (wgs == 0 || wgs > cap) wgs = cap;
-    const size_t ev = rb == 2 ? 128 + 64 : 192 + 128;
+    const size_t ev = rb == 2 ? 128 + 64 : (rb == 3 ? 192 + 128 : QMPC_BIG_LD + 192);
     HIP_TRY(c, hipMalloc(&c->d_wk_ovf[k], sizeof(double) * wgs * QMPC_ENGINE_OVF_EVENTS * ev));
   }
   c->wk_cap[k] = (int)cap;
@@ -635,6 +651,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     k0 = 3;
     nclass_eff = 4;
   }
+  const bool long_h = h > QMPC_LONG_HORIZON;
   for (int k = k0; k < nclass_eff; ++k) {
     P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
     P.count = k > k0 ? cnt + (k - 1) : nullptr;
@@ -643,6 +660,10 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     const bool more = k + 1 < nclass_eff;
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;
+    if (long_h && chain[k] == 3) {  // robots beyond 192 rows go on to the large-problem producer
+      P.next_list = c->d_lists + (size_t)3 * c->max_batch;
+      P.next_count = cnt + QMPC_CNT_BIG;
+    }
     // the first class of the chain: one workgroup per robot; the later ones: one per resident slot, the list
     // is consumed as a queue (no workgroup is dispatched only to find its list entry missing)
     const bool listed = k > k0;
@@ -740,6 +761,55 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       if (res > 0 && res < grid) grid = res;
     }
     HIP_TRY(c, qmpc_launch(chain[k], &P, grid, stream));
+  }
+  if (long_h) {
+    // ---- the large problems (192 < n_r <= 432: all feet down beyond 16 segments, a trot beyond 32): H in global memory, block
+    // sweep, the seven-block engine; what that engine cannot hold is REPORTED (the one-kernel path's stage 0 finds no class for
+    // it: QMPC_ST_WS_FULL, zero forces).  Normally the list is empty: two launches that find nothing to do
+    if (const int rc = ensure_split(c, 5)) return rc;
+    QmpcParams A = P;
+    A.list = c->d_lists + (size_t)3 * c->max_batch;
+    A.count = cnt + QMPC_CNT_BIG;
+    A.qhead = cnt + QMPC_CNT_BIG + 1;
+    A.clear_counts = nullptr;
+    A.next_list = nullptr; A.next_count = nullptr;
+    A.list_hi = 0x7fffffff;
+    A.rid0 = 0;
+    A.wk_hinv = c->d_wk_hinv[2]; A.wk_xu = c->d_wk_xu[2]; A.wk_hdr = c->d_wk_hdr[2]; A.wk_order = c->d_wk_order[2];
+    A.wk_ovf = c->d_wk_ovf[2];
+    A.wk_ld = QMPC_BIG_LD; A.wk_cap = c->wk_cap[2]; A.wk_base = 0;
+    A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
+    A.wk_block = 0;
+    A.wk_count = cnt + QMPC_CNT_BIG + 2;
+    A.wk_qhead = cnt + QMPC_CNT_BIG + 3;
+    A.wk_bucket = cnt + QMPC_CNT_BIG + 4;
+    A.fb_list = c->d_fb_lists;  // (class 2's hand-back list is not in use at these horizons)
+    A.fb_count = cnt + QMPC_CNT_BIG + 4 + QMPC_ORDER_BUCKETS;
+    A.status_or = 0;
+    int gp = batch;
+    {
+      const int res = qmpc_resident_blocks(3);  // (the producer has the 192-row class's footprint: one workgroup per CU)
+      if (res > 0 && res < gp) gp = res;
+    }
+    HIP_TRY(c, qmpc_big_launch(&A, gp, stream));
+    QmpcParams B = A;
+    B.list = nullptr; B.count = nullptr; B.qhead = nullptr;
+    int gb = batch;
+    {
+      const int res = qmpc_engine_resident(5);
+      if (res > 0 && res < gb) gb = res;
+    }
+    HIP_TRY(c, qmpc_engine_launch(5, &B, gb, stream));
+    QmpcParams F = P;  // what the engine handed back: reported by the one-kernel path (no class takes n_r > 192)
+    F.list = A.fb_list; F.count = A.fb_count; F.qhead = cnt + QMPC_CNT_BIG + 5 + QMPC_ORDER_BUCKETS; F.clear_counts = nullptr;
+    F.list_hi = 0x7fffffff;
+    F.next_list = nullptr; F.next_count = nullptr;
+    int gf = batch;
+    {
+      const int res = qmpc_resident_blocks(3);
+      if (res > 0 && res < gf) gf = res;
+    }
+    HIP_TRY(c, qmpc_launch(3, &F, gf, stream));
   }
   return QMPC_OK;
 }

@@ -34,11 +34,15 @@
 //   bucket by bucket -- a launch ends with its slowest robot, which must not be the one that started last)
 #define QMPC_MAX_CHUNKS 8
 #define QMPC_ORDER_BUCKETS 16
-#define QMPC_COUNTERS (64 + 2 * QMPC_MAX_CHUNKS * QMPC_ORDER_BUCKETS)
+//   the large problems (horizons > 16, n_r > 192) from QMPC_CNT_BIG: [+0] list length  [+1] the producer's queue head  [+2] work
+//   items produced  [+3] the engine's queue head  [+4 .. +19] order buckets  [+20] robots handed back  [+21] their queue head
+#define QMPC_CNT_BIG (64 + 2 * QMPC_MAX_CHUNKS * QMPC_ORDER_BUCKETS)
+#define QMPC_COUNTERS (QMPC_CNT_BIG + 8 + QMPC_ORDER_BUCKETS)
 
 // decoupled path: a sweep workgroup (or the long-horizon producer) leaves its robot's explicit inverse,
 // unconstrained minimiser and stance list in a work item; single-robot engine workgroups consume the items
 #define QMPC_ENGINE_OVF_EVENTS 160 // events per engine workgroup in the overflow pool (beyond its registers and LDS)
+#define QMPC_BIG_LD 448  // leading dimension of a large problem's work item (n_r <= 432 = 12 x 36; seven 64-row blocks)
 #define QMPC_WK_SLOTS_MAX 192  // stance slots an item can describe (three 64-lane groups; trot at horizon 36 has 72)
 struct QmpcWorkHdr {
   int rid, n, nst, status0;              // robot, reduced size 3 nst, stance foot-steps, status bits so far

@@ -1363,6 +1363,9 @@ typedef EngineEntry<2, 1, 1, 4, 23, 42> Engine2;
 // phase is bound by the number of robots in flight, not by the slowest robot): 3 holders x 13 events + 25 in LDS, the
 // rest of an unusually long history in the overflow pool
 typedef EngineEntry<3, 2, 1, 4, 13, 25> Engine3;
+// engine of the large problems (192 < n_r <= 432: seven row blocks, 192 working slots, up to 144 stance foot-steps): 20 VGPRs
+// per event -- 3 holders x 6 in registers, 24 in LDS, the rest of the (long) histories in the overflow pool; one workgroup per CU
+typedef EngineEntry<7, 3, 3, 4, 2, 24> Engine7;
 static_assert(sizeof(ESmem<Engine3::C>) <= 80 * 1024 && sizeof(ESmem<Engine2::C>) <= 80 * 1024, "two engine workgroups per CU");
 
 }  // namespace
@@ -1370,12 +1373,18 @@ static_assert(sizeof(ESmem<Engine3::C>) <= 80 * 1024 && sizeof(ESmem<Engine2::C>
 extern "C" hipError_t qmpc_engine_prepare(void) {
   hipError_t e = Engine2::prepare();
   if (e != hipSuccess) return e;
+  if ((e = Engine7::prepare()) != hipSuccess) return e;
   return Engine3::prepare();
 }
-extern "C" int qmpc_engine_resident(int rb) { return rb == 2 ? Engine2::resident() : (rb == 3 ? Engine3::resident() : 0); }
-extern "C" int qmpc_engine_capacity(int rb) { return rb == 2 ? Engine2::C::KEV : (rb == 3 ? Engine3::C::KEV : 0); }
+extern "C" int qmpc_engine_resident(int rb) {  // (rb 5: the large problems)
+  return rb == 2 ? Engine2::resident() : (rb == 3 ? Engine3::resident() : (rb == 5 ? Engine7::resident() : 0));
+}
+extern "C" int qmpc_engine_capacity(int rb) {
+  return rb == 2 ? Engine2::C::KEV : (rb == 3 ? Engine3::C::KEV : (rb == 5 ? Engine7::C::KEV : 0));
+}
 extern "C" hipError_t qmpc_engine_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream) {
   if (rb == 2) return Engine2::launch(P, grid, stream);
   if (rb == 3) return Engine3::launch(P, grid, stream);
+  if (rb == 5) return Engine7::launch(P, grid, stream);
   return hipErrorInvalidValue;
 }

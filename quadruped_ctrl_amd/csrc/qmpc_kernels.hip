@@ -186,8 +186,11 @@ struct Smem {
   using C = Cfg<RB>;
   // ---- live for the whole solve
   QmpcParams par;  // kernel parameters parked in LDS (keeps ~45 uniforms out of SGPRs)
-  double fmaxk[64];
-  unsigned char sidx[64];
+  // stance foot-steps a workgroup can list: 64 (n_r <= 192) -- 144 in the 192-row class's instantiations, whose producer
+  // for the LARGE problems (n_r up to 432 = 12 x 36, matrix in global memory: big_tail) shares stages 0 - 1 with them
+  static constexpr int SLOTS = (RB == 3) ? 144 : 64;
+  double fmaxk[SLOTS];
+  unsigned char sidx[SLOTS];
   unsigned char kslot[4 * C::HMAX];  // foot-step k -> stance slot (0xff = swing): inverse of sidx, for the warm start
   int nst, status;
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
@@ -257,7 +260,7 @@ struct Smem {
 // minimiser as below, then the inverse goes to the robot's work item in global memory (L2 / Infinity-Cache
 // resident) instead of LDS and the workgroup moves on; the active set is run by qmpc_engine_kernel
 // (qmpc_engine.hip) -- a workgroup of the large classes no longer pins a whole CU while one of its waves iterates.
-template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false, bool PHA = false>
+template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false, bool PHA = false, bool BIG = false>
 __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
@@ -433,11 +436,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       const bool st = fs < nfs && ((ADMM && PK.admm_mode == 1) ? true : !(fm < 0.01f && fm > -.01f));  // :64-67
       const unsigned long long mask = __ballot(st);
       const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
-      if (st && pos < 64) {  // (more than 64 stance foot-steps: n_r > 192, no class takes the robot -- reported below)
+      if (st && pos < Smem<RB>::SLOTS) {  // (beyond 64 stance foot-steps, n_r > 192: the large-problem producer's robots)
         S.sidx[pos] = (unsigned char)fs;
         S.fmaxk[pos] = (double)fm;
       }
-      if (fs < 4 * HMAX) S.kslot[fs] = (st && pos < 64) ? (unsigned char)pos : (unsigned char)0xff;
+      if (fs < 4 * HMAX) S.kslot[fs] = (st && pos < Smem<RB>::SLOTS) ? (unsigned char)pos : (unsigned char)0xff;
       base += __popcll(mask);
     }
     if (tid == 0) {
@@ -576,7 +579,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     P.f_ff[(size_t)rid * 12 + l12] =
         qmpc_cmd_f2b(P.c_r_body + (size_t)rid * 9 + 3 * ii, fb[3 * leg], fb[3 * leg + 1], fb[3 * leg + 2]);
   };
-  if (nst == 0 || n > NP) {
+  static_assert(!BIG || (RB == 3 && PHA && !ADMM && !WARM), "large-problem producer: an instantiation of the 192-row class");
+  if (nst == 0 || n > (BIG ? 3 * Smem<RB>::SLOTS : NP)) {
     // all-swing: q_soln is all zeros (SolverMPC.cpp:545-551).  Too large for
     // this instantiation: hand the robot to the next size class.
     if (nst == 0) {
@@ -661,6 +665,214 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   }
   __syncthreads();  // ---- barrier 2
   QMPC_TICK(2);
+
+  if constexpr (BIG) {
+    // ------------------------------------------------------------ the large problems (192 < n_r <= 432)
+    // The reference's interface takes up to K_MAX_GAIT_SEGMENTS = 36 segments: all four feet down at 36 segments is
+    // n_r = 432, a trot 216.  Nothing of that size fits the register file: H is written to the robot's work item in
+    // global memory (448 x 448), inverted there by a symmetric BLOCK sweep -- 16 pivots per step: the pivot block
+    // factorised in LDS, the pivot columns C and F = C P^-1 (through the factor) staged in LDS, A <- A - F C^T through L2, the same sweep
+    // operator as stage 3 (A ends as -H^-1) -- and handed to the engine kernel like every other work item.  This path is
+    // about coverage of the interface, not speed: ~3 ms per robot and CU (the reference's dense qpOASES needs seconds).
+    constexpr int LDB = QMPC_BIG_LD, NB = 16, PD = NB + 1, NMAX = 3 * Smem<RB>::SLOTS;
+    const int item = S.evslot;
+    GlobalF64* const A = (GlobalF64*)P.wk_hinv + (size_t)item * ((size_t)LDB * LDB);
+    auto ldA = [&](int r, int cidx) __attribute__((always_inline)) {  // (past the L1: other waves wrote it)
+      return __hip_atomic_load(A + (size_t)r * LDB + cidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const int wv = tid >> 6;
+    constexpr int NWV = NT / 64;
+    const double dm2 = x_drag * inv_m * inv_m;
+    // ---- g (one variable per thread: n <= 432 < 768), as in stage 2
+    double gmine = 0.0;
+    if (tid < n) {
+      const int ki = S.sidx[tid / 3], ax = tid % 3;
+      const int st = ki >> 2, b = ki & 3;
+      const double* s0 = &Aa.s[0][st * 12];
+      const double* s1 = &Aa.s[1][st * 12];
+      double acc = s0[9 + ax] * inv_m + s1[3 + ax] * inv_m;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) acc += Aa.Mb[b][3 * l + ax] * s0[6 + l] + Aa.Nb[b][3 * l + ax] * s1[l];
+      if (drag && ax == 0) acc += (x_drag * inv_m) * (s1[11] + Aa.s[2][st * 12 + 5]);
+      gmine = 2.0 * acc;
+    }
+    // ---- H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I) element by element (SolverMPC.cpp:395): a wave per
+    // row, lanes along the columns
+    {
+      const double w11 = Aa.W[11] * dm2, w5 = Aa.W[5] * dm2, w5x = Aa.W[5] * (x_drag * dm2);
+      for (int r = wv; r < n; r += NWV) {
+        const int ki = S.sidx[r / 3], ai = r % 3, si = ki >> 2, u = 3 * (ki & 3) + ai;
+        for (int j = lane; j < n; j += 64) {
+          const int kj = S.sidx[j / 3], cax = j % 3, sj = kj >> 2;
+          const int cidx = si * h + sj, tidx = sj * h + si, eidx = u * 12 + 3 * (kj & 3) + cax;
+          double v = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
+          if (drag) {
+            double add = 0.0;
+            if (ai == 2 && cax == 0) add = Aa.ct1[cidx] * w11 + Aa.ct5[cidx] * w5;
+            if (ai == 0 && cax == 2) add = Aa.ct1[tidx] * w11 + Aa.ct5[tidx] * w5;
+            if (ai == 0 && cax == 0) add = Aa.ct8[cidx] * w5x;
+            v += add;
+          }
+          A[(size_t)r * LDB + j] = 2.0 * (v + ((r == j) ? alpha : 0.0));
+        }
+      }
+    }
+    __syncthreads();  // (the tables are dead: the union becomes scratch; the rows of H are in L2)
+    double* const Cp = reinterpret_cast<double*>(&S.u);  // C[NMAX][PD]: the pivot columns
+    double* const Fp = Cp + NMAX * PD;                    // F[NMAX][PD] = C P^-1
+    double* const Pm = Fp + NMAX * PD;                    // the pivot block, then its Cholesky factor L [NB][PD]
+    double* const Qm = Pm + NB * PD;                      // L^-1
+    double* const Rm = Qm + NB * PD;                      // P^-1 = L^-T L^-1
+    double* const gl = Rm + NB * PD;                      // g [NMAX]
+    static_assert(sizeof(double) * (2 * NMAX * PD + 3 * NB * PD + NMAX) <= sizeof(S.u), "scratch of the block sweep");
+    if (tid < NMAX) gl[tid] = gmine;
+    bool bad = false;
+#pragma unroll 1
+    for (int k0 = 0; k0 < n; k0 += NB) {
+      const int bsz = (n - k0 < NB) ? n - k0 : NB;
+      // 1. pivot block (identity-padded) and pivot columns -> LDS
+      if (tid < NB * NB) {
+        const int pi = tid / NB, pj = tid % NB;
+        Pm[pi * PD + pj] = (pi < bsz && pj < bsz) ? ldA(k0 + pi, k0 + pj) : ((pi == pj) ? 1.0 : 0.0);
+      }
+      for (int e = tid; e < n * NB; e += NT) {
+        const int r = e / NB, kk = e % NB;
+        Cp[r * PD + kk] = (kk < bsz) ? ldA(r, k0 + kk) : 0.0;
+      }
+      __syncthreads();
+      // 2. P = L L^T in place (the lower triangle of Pm becomes L).  NOT an explicit Gauss-Jordan inverse of the block: the
+      // four feet of a step push the body almost identically, a 16 x 16 block of the sweep state has eigenvalues down to
+      // the regulariser alpha, and F = C P^-1 through an unpivoted explicit inverse loses the digits the whole sweep
+      // needs (measured on all feet down at 36 segments: H^-1 to 1e-1 -- through the factor: 4e-12; oracle-side study)
+#pragma unroll 1
+      for (int pp = 0; pp < NB; ++pp) {
+        double vnew = 0.0;
+        const int pi = tid / NB, pj = tid % NB;
+        if (tid < NB * NB) {
+          const double d = Pm[pp * PD + pp], vo = Pm[pi * PD + pj];
+          bad |= !(d > 0.0);
+          const double lpp = __builtin_sqrt(d);
+          vnew = vo;
+          if (pj == pp && pi == pp) vnew = lpp;
+          else if (pj == pp && pi > pp) vnew = vo / lpp;
+          else if (pi > pp && pj > pp) vnew = vo - (Pm[pi * PD + pp] / lpp) * (Pm[pj * PD + pp] / lpp);
+        }
+        __syncthreads();
+        if (tid < NB * NB) Pm[pi * PD + pj] = vnew;
+        __syncthreads();
+      }
+      // 2b. L^-1 (one column per thread, forward substitution) and P^-1 = L^-T L^-1 for the pivot block itself
+      if (tid < NB) {
+        double x[NB];
+#pragma unroll
+        for (int i2 = 0; i2 < NB; ++i2) {
+          double acc = (i2 == tid) ? 1.0 : 0.0;
+#pragma unroll
+          for (int m = 0; m < i2; ++m) acc = __builtin_fma(-Pm[i2 * PD + m], (m >= tid) ? x[m] : 0.0, acc);
+          x[i2] = (i2 >= tid) ? acc / Pm[i2 * PD + i2] : 0.0;
+          Qm[i2 * PD + tid] = x[i2];
+        }
+      }
+      __syncthreads();
+      if (tid < NB * NB) {
+        const int pi = tid / NB, pj = tid % NB;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc = __builtin_fma(Qm[m * PD + pi], Qm[m * PD + pj], acc);
+        Rm[pi * PD + pj] = acc;
+      }
+      // 3. F = C P^-1 row by row through the factor: L y = C_r^T, L^T f = y
+      if (tid < n) {
+        double y[NB];
+#pragma unroll
+        for (int i2 = 0; i2 < NB; ++i2) {
+          double acc = Cp[tid * PD + i2];
+#pragma unroll
+          for (int m = 0; m < i2; ++m) acc = __builtin_fma(-Pm[i2 * PD + m], y[m], acc);
+          y[i2] = acc / Pm[i2 * PD + i2];
+        }
+#pragma unroll
+        for (int i2 = NB - 1; i2 >= 0; --i2) {
+          double acc = y[i2];
+#pragma unroll
+          for (int m = i2 + 1; m < NB; ++m) acc = __builtin_fma(-Pm[m * PD + i2], y[m], acc);
+          y[i2] = acc / Pm[i2 * PD + i2];
+          Fp[tid * PD + i2] = y[i2];
+        }
+      }
+      __syncthreads();
+      // 4. the sweep step: off-block A -= F C^T ; pivot columns / rows <- F ; pivot block <- -P^-1
+      for (int r = wv; r < n; r += NWV) {
+        const bool rin = (unsigned)(r - k0) < (unsigned)bsz;
+        double fr[NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) fr[m] = Fp[r * PD + m];
+        for (int j = lane; j < n; j += 64) {
+          const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
+          double v;
+          if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
+          else if (jin) v = Fp[r * PD + (j - k0)];
+          else if (rin) v = Fp[j * PD + (r - k0)];
+          else {
+            v = ldA(r, j);
+#pragma unroll
+            for (int m = 0; m < NB; ++m) v = __builtin_fma(-fr[m], Cp[j * PD + m], v);
+          }
+          A[(size_t)r * LDB + j] = v;
+        }
+      }
+      __syncthreads();  // (every store of the step is in L2 before the next step reads)
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+      if (tid == 0) S.status |= QMPC_DEV_ST_NOT_PD;
+    }
+    // ---- A = -H^-1: x_u = A g; the work item gets +H^-1 (full matrix: the engine's lower-triangle reads find it all)
+    for (int r = wv; r < n; r += NWV) {
+      double acc = 0.0;
+      for (int j = lane; j < n; j += 64) {
+        const double v = ldA(r, j);
+        acc = __builtin_fma(v, gl[j], acc);
+        A[(size_t)r * LDB + j] = -v;
+      }
+#pragma unroll
+      for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
+      if (lane == 0) Fp[r] = acc;  // (x_u, parked beside g)
+    }
+    __syncthreads();
+    constexpr int LDX = QMPC_BIG_LD;
+    if (tid < LDX) P.wk_xu[(size_t)item * LDX + tid] = (tid < n) ? Fp[tid] : 0.0;
+    QmpcWorkHdr* const hd = P.wk_hdr + item;
+    if (tid < QMPC_WK_SLOTS_MAX) {
+      hd->sidx[tid] = (tid < Smem<RB>::SLOTS) ? S.sidx[tid] : (unsigned char)0;
+      hd->fmaxk[tid] = (tid < nst) ? (float)S.fmaxk[tid] : 0.f;
+    }
+    if (tid == 0) {
+      hd->rid = rid;
+      hd->n = n;
+      hd->nst = nst;
+      hd->status0 = S.status;
+    }
+    if (tid < WAVE) {
+      // (hardest robots first, as in the other producers: rows violated at x_u)
+      int viol = 0;
+      for (int sl = tid; sl < nst; sl += 64) {
+        const double x0 = Fp[3 * sl], x1 = Fp[3 * sl + 1], x2 = Fp[3 * sl + 2];
+        const double fx = P.mu_inv * x0, fy = P.mu_inv * x1, nt = -P.tol, ifr = P.inv_fr_norm;
+        viol += ((fx + x2) * ifr < nt) + ((x2 - fx) * ifr < nt) + ((fy + x2) * ifr < nt) + ((x2 - fy) * ifr < nt) +
+                (S.fmaxk[sl] - x2 < nt);
+      }
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) viol += __shfl_xor(viol, sft);
+      if (tid == 0) {
+        const int lvl = viol >> 4;
+        const int b = QMPC_ORDER_BUCKETS - 1 - (lvl < QMPC_ORDER_BUCKETS - 1 ? lvl : QMPC_ORDER_BUCKETS - 1);
+        const int pos = atomicAdd(P.wk_bucket + b, 1);
+        P.wk_order[(size_t)b * P.wk_cap + P.wk_base + pos] = item;
+      }
+    }
+    __syncthreads();
+    return false;
+  }
 
   // ------------------------------------------------------------ stage 2
   // gradient g_red -> LDS, Hessian rows straight into registers.
@@ -2675,6 +2887,32 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES_A) void qmpc_sweep_
   }
 }
 
+// Producer of the LARGE problems (192 < n_r <= 432; solve_one<..., BIG>): list-consuming, one workgroup per CU (its block
+// sweep uses the whole union as scratch).  Built with the 192-row class's translation unit.
+template <bool CMD>
+__global__ __launch_bounds__(Cfg<3>::NT, Cfg<3>::MIN_WAVES) void qmpc_big_kernel(const QmpcParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
+  Smem<3>& S = *reinterpret_cast<Smem<3>*>(qmpc_smem);
+  const int nlist = *P.count;
+  if ((int)blockIdx.x >= nlist) return;  // uniform
+  for (int idx = (int)blockIdx.x;;) {
+    const int rid = P.list[idx];
+    int tid1 = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid1));
+    __builtin_assume(tid1 >= 0 && tid1 < Cfg<3>::NT);
+    typedef const __attribute__((address_space(4))) QmpcParams* KernargPtr;
+    KernargPtr pk = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pk));
+    const QmpcParams& PK = *(const QmpcParams*)pk;
+    solve_one<3, true, CMD, false, false, true, true>(rid, tid1, S, PK);
+    __syncthreads();
+    if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+    __syncthreads();
+    idx = S.qnext;
+    if (idx >= nlist) break;  // uniform
+  }
+}
+
 namespace {
 // LDS of the producer: everything but the active-set storage
 template <int RB>
@@ -2799,6 +3037,17 @@ QMPC_DEFINE_CLASS(2)
 #endif
 #if !defined(QMPC_RB) || QMPC_RB == 3
 QMPC_DEFINE_CLASS(3)
+extern "C" hipError_t qmpc_big_prepare(void) {
+  hipError_t e = set_smem(qmpc_big_kernel<false>, sizeof(Smem<3>));
+  if (e != hipSuccess) return e;
+  return set_smem(qmpc_big_kernel<true>, sizeof(Smem<3>));
+}
+extern "C" hipError_t qmpc_big_launch(const QmpcParams* P, int grid, hipStream_t stream) {
+  const dim3 g(grid), b(Cfg<3>::NT);
+  if (P->c_position != nullptr) hipLaunchKernelGGL((qmpc_big_kernel<true>), g, b, sizeof(Smem<3>), stream, *P);
+  else hipLaunchKernelGGL((qmpc_big_kernel<false>), g, b, sizeof(Smem<3>), stream, *P);
+  return hipGetLastError();
+}
 #endif
 #if !defined(QMPC_RB) || QMPC_RB == 4
 QMPC_DEFINE_CLASS(4)

@@ -145,13 +145,15 @@ def make_trot(batch, horizon, seed=55):
 
 def make_long_horizon(batch, horizon, gait="trot", seed=77):
     """Long horizons (17 .. 36 = K_MAX_GAIT_SEGMENTS, convexMPC_interface.h:3): `gait` = "trot" (offsets 0, h/2, h/2, 0,
-    durations h/2: n_r = 6 h, the 192-row class up to horizon 32) or "bound" (the reference's bounding rescaled:
-    offsets h/2, h/2, 0, 0, durations 0.4 h: n_r ~ 4.7 h, <= 192 up to horizon 36)."""
+    durations h/2: n_r = 6 h, the 192-row class up to horizon 32), "bound" (the reference's bounding rescaled:
+    offsets h/2, h/2, 0, 0, durations 0.4 h: n_r ~ 4.7 h, <= 192 up to horizon 36) or "stand" (n_r = 12 h)."""
     rng = np.random.default_rng(SEED0 + seed + horizon)
     d = _states(rng, batch, horizon)
     hh = horizon // 2
     if gait == "trot":
         table = {"g": ((0, hh, hh, 0), (hh,) * 4)}
+    elif gait == "stand":   # all four feet down for the whole horizon: n_r = 12 h (432 at horizon 36: the large-problem path)
+        table = {"g": ((0, 0, 0, 0), (horizon,) * 4)}
     else:
         dur = (2 * horizon) // 5
         table = {"g": ((hh, hh, 0, 0), (dur,) * 4)}

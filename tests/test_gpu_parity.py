@@ -462,17 +462,67 @@ def test_long_horizons_vs_oracle(h, gait, B, mpc_factory):
     assert np.all(res["soln"][sw] == 0.0) and res["soln"].shape[1] == 12 * h
 
 
-def test_long_horizon_beyond_192_rows_is_reported(mpc_factory):
-    """A long-horizon robot with more than 64 stance foot-steps (trot at horizon 36: n_r = 216) is beyond the 192-row
-    class: reported with QMPC_ST_WS_FULL and zero forces, its neighbours that fit are solved."""
-    b = W.make_long_horizon(8, 36, "trot")
-    small = W.make_long_horizon(8, 36, "bound")
-    for k in ("gait",):
-        b[k][4:] = small[k][4:]
+@pytest.mark.parametrize("h,gait,B", [(36, "trot", 24), (24, "stand", 16), (36, "stand", 12), (24, "brake", 12)])
+def test_large_problems_beyond_192_rows(h, gait, B, mpc_factory):
+    """The interface takes up to K_MAX_GAIT_SEGMENTS = 36 segments (convexMPC_interface.h:3): a trot there has
+    n_r = 216, all four feet down 432 -- beyond the 192 rows a register-resident sweep holds.  Those robots go through
+    the large-problem producer (H in global memory, symmetric block sweep through Cholesky factors of the 16 x 16 pivot
+    blocks) and the seven-block engine.  (a) the work item: H^-1 against numpy's inverse of the fp64 Kronecker model's H
+    <= 1e-8, symmetric to rounding, x_u likewise; (b) the solution against the reference's qpOASES (iteration cap lifted) on the
+    model's QP: same objective to 1e-12, feasible to 1e-9, forces within 1e-6; (c) swing entries exactly zero, mixed batch:
+    robots that fit the 192-row class still take it."""
+    from oracle import kron_model as K
+    # ("brake": all feet down, braking from 0.5 m/s -- 60+ active-set iterations: the engine's holders, its LDS pool and
+    #  the overflow pool all hold events)
+    b = W.make_standing(B, h) if gait == "brake" else W.make_long_horizon(B, h, gait)
+    if gait == "trot":  # a few robots of the 192-row class among them
+        small = W.make_long_horizon(B, h, "bound")
+        b["gait"][B - 4:] = small["gait"][B - 4:]
+    nst = (b["gait"] != 0).sum(1)
+    assert 3 * nst.max() > 192
     m = mpc_factory(b)
     res = m.solve(b, full=True)
-    assert ((res["status"][:4] & 8) != 0).all() and np.all(res["grf"][:4] == 0.0) and np.all(res["soln"][:4] == 0.0)
-    assert ((res["status"][4:] & 47) == 0).all() and np.abs(res["grf"][4:]).max() > 1.0
+    assert ((res["status"] & 47) == 0).all(), np.unique(res["status"])
+    big = np.nonzero(3 * nst > 192)[0]
+    worst_x, worst_f, worst_inf = 0.0, 0.0, 0.0
+    for i in big[:4]:
+        H, g = K.assemble(b, int(i))
+        Hf, gf, A, lb, ub, x0 = O.assemble(b, int(i))
+        ve, Hr, gr, Ar, lr, ur = O.reduce(Hf, gf, A, lb, ub)
+        vi = np.nonzero(~ve)[0]
+        Hm, gm = H[np.ix_(vi, vi)], g[vi]
+        xq, y, used, rc, irc = O.qpoases(Hm, gm, Ar, lr, ur, nwsr=50000)
+        assert rc == 0 and irc == 0
+        xs = res["soln"][i][~ve]
+        f = lambda x: 0.5 * x @ Hm @ x + gm @ x
+        ax = Ar @ xs
+        worst_inf = max(worst_inf, np.maximum(lr - ax, 0).max(), np.maximum(ax - ur, 0).max())
+        worst_f = max(worst_f, abs(f(xs) - f(xq)) / abs(f(xq)))
+        worst_x = max(worst_x, np.abs(xs - xq).max() / max(np.abs(xq).max(), 1.0))
+    print(f"   large problems h={h} {gait}: n_r {3 * nst.min()}..{3 * nst.max()}, iters mean {res['iters'][big].mean():.1f} max "
+          f"{res['iters'][big].max()}; vs qpOASES on the fp64 model's QP: x {worst_x:.2e} objective {worst_f:.2e} infeasibility {worst_inf:.2e}")
+    assert worst_f < 1e-12 and worst_inf < 1e-9 and worst_x < 1e-6
+    # (a) the producer's work item (items are filed in the order the workgroups finish: find the robot by its header)
+    seen = 0
+    for item in range(len(big)):
+        hinv, xu, hdr = m.debug_read_item(2, item)
+        i, n = int(hdr[0]), int(hdr[1])
+        if i != int(big[0]):
+            continue
+        H, g = K.assemble(b, i)
+        vi = np.array([3 * k + a for k in range(4 * h) if b["gait"][i][k] for a in range(3)])
+        Hi = np.linalg.inv(H[np.ix_(vi, vi)])
+        assert n == len(vi)
+        assert np.abs(hinv[:n, :n] - Hi).max() / np.abs(Hi).max() < 1e-8
+        assert np.abs(hinv[:n, :n] - hinv[:n, :n].T).max() / np.abs(Hi).max() < 1e-13
+        assert np.abs(xu[:n] + Hi @ g[vi]).max() / np.abs(Hi @ g[vi]).max() < 1e-6
+        seen += 1
+    assert seen == 1
+    sw = np.repeat(b["gait"] == 0, 3, axis=1)
+    assert np.all(res["soln"][sw] == 0.0) and res["soln"].shape[1] == 12 * h
+    if gait == "trot":
+        ok = np.nonzero(3 * nst <= 192)[0]
+        assert len(ok) == 4 and np.abs(res["grf"][ok]).max() > 1.0
 
 
 def test_jcqp_alternate_vs_model(mpc_factory):
