@@ -25,8 +25,8 @@
 #define QMPC_C_LINKAGE
 #endif
 
-/* reference :40  (horizon <= 36 = K_MAX_GAIT_SEGMENTS like the reference; beyond 16 segments the robot must have at most
- * 64 stance foot-steps in the horizon, see QMPC_MAX_HORIZON in qmpc.h) */
+/* reference :40  (horizon <= 36 = K_MAX_GAIT_SEGMENTS like the reference, any gait; see QMPC_MAX_HORIZON in qmpc.h for the
+ * routes the long ones take) */
 QMPC_C_LINKAGE void setup_problem(double dt, int horizon, double mu, double f_max);
 /* reference :41  double-precision (MATLAB) twin of the floats entry */
 QMPC_C_LINKAGE void update_problem_data(double* p, double* v, double* q, double* w,

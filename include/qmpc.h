@@ -50,11 +50,14 @@ extern "C" {
 
 #define QMPC_MAX_HORIZON 36 /* K_MAX_GAIT_SEGMENTS (src/MPC_Ctrl/convexMPC_interface.h:3).  The reference's own gaits
                                use 10 .. 16 segments (ConvexMPCLocomotion.cpp:25,196,204): every size class takes those.
-                               Longer horizons (17 .. 36) are assembled by the 192-row class only, i.e. for robots with
-                               at most 64 stance foot-steps in the horizon (n_r = 3 x stance foot-steps <= 192: trot up
-                               to 32 segments, gaits with a duty factor <= 0.44 up to 36); a robot with more is reported
-                               with QMPC_ST_WS_FULL (zero forces), like any robot beyond a size hint */
-#define QMPC_LONG_HORIZON 16 /* horizons above this take the long-horizon route described above */
+                               Longer horizons (17 .. 36) are assembled by the 192-row class (robots with at most 64
+                               stance foot-steps in the horizon, n_r = 3 x stance foot-steps <= 192: trot up to 32
+                               segments, gaits with a duty factor <= 0.44 up to 36) and, beyond that, by the
+                               LARGE-PROBLEM path (n_r up to 432 = all four feet down for 36 segments: the Hessian in
+                               global memory, a block sweep, a seven-block engine; ~1e5 QP solves/s instead of ~1e6 --
+                               coverage of the interface, not a fast path; 1.6 MiB of device memory per robot of the
+                               handle's max_batch, allocated on the first call at such a horizon) */
+#define QMPC_LONG_HORIZON 16 /* horizons above this take the long-horizon routes described above */
 
 /* return codes */
 #define QMPC_OK 0

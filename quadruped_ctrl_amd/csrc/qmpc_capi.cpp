@@ -646,7 +646,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   if (h > QMPC_LONG_HORIZON) {
     // long horizons (up to K_MAX_GAIT_SEGMENTS = 36): the 192-row class alone has the threads (12 h tracking-error
     // entries, one per thread) and the LDS (h x h coefficient tables) to assemble them -- it takes every robot; one with
-    // more than 64 stance foot-steps is reported (QMPC_ST_WS_FULL)
+    // more than 64 stance foot-steps goes on to the large-problem path below
     if (full_problem) return QMPC_ERR_ARG;  // (use_jcqp = 1 keeps all 12 h variables: beyond 192 rows)
     k0 = 3;
     nclass_eff = 4;
