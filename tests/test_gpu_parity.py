@@ -579,6 +579,30 @@ def test_jcqp_alternate_vs_model(mpc_factory):
             assert np.array_equal(m.solve(b, full=True)["soln"], exact)      # back to the exact solve
 
 
+def test_reference_shim_at_the_interface_maximum_of_36_segments():
+    """setup_problem(horizon = K_MAX_GAIT_SEGMENTS) through the reference's six functions, for a trot (n_r = 216) and with
+    all four feet down (n_r = 432): the large-problem path behind the shim.  Bit for bit the batched C ABI's result (same
+    kernels, same record), and get_solution past the horizon reads 0."""
+    lib = _shim()
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC
+    for gait in ("trot", "stand"):
+        b = W.make_long_horizon(2, 36, gait)
+        m = BatchedConvexMPC(0, max_batch=2, max_horizon=36)
+        m.setup(b["dt"], 36, b["mu"], b["f_max"])
+        batched = m.solve(b, full=True)
+        m.close()
+        assert ((batched["status"] & 47) == 0).all()
+        for i in range(2):
+            sol = _shim_solve(lib, b, i)
+            assert lib.qmpc_shim_last_status() == 0
+            assert sol.shape == (12 * 36,) and np.array_equal(sol, batched["soln"][i])
+            assert np.abs(sol).max() > 1.0 and lib.get_solution(12 * 36) == 0.0
+    # ... and back to a reference-sized horizon afterwards
+    b = W.make_config(1, batch=1)
+    sol = _shim_solve(lib, b, 0)
+    assert lib.qmpc_shim_last_status() == 0 and np.abs(sol).max() > 1.0
+
+
 def test_reference_shim_use_jcqp():
     """update_solver_settings(..., use_jcqp): 0 = exact solve; 1 / 2 = the reference's ADMM alternate with the
     knobs of that very call (convexMPC_interface.cpp:107-119), the double thresholded like the reference."""

@@ -27,6 +27,10 @@ run trot_h16 --config 3
 # long horizons (the 192-row class + the decoupled engine): trot at 24 segments, bounding-type gait at 36
 python $R/bench.py --steps 100 --workload long-trot --horizon 24 --no-cpu-all-cores > $OUT/bench_long_trot_h24.json 2> $OUT/bench_long_trot_h24.err
 python $R/bench.py --steps 50 --workload long-bound --horizon 36 --no-cpu-all-cores > $OUT/bench_long_bound_h36.json 2> $OUT/bench_long_bound_h36.err
+# the large-problem path (192 < n_r <= 432): a trot at 36 segments, all feet down at 24 (braking) and 36 segments
+python $R/bench.py --steps 30 --warmup 3 --workload long-trot --horizon 36 --no-cpu-all-cores --no-pipelined > $OUT/bench_large_trot_h36.json 2> $OUT/bench_large_trot_h36.err
+python $R/bench.py --steps 20 --warmup 3 --workload standing --horizon 24 --no-cpu-all-cores --no-pipelined > $OUT/bench_large_standing_h24.json 2> $OUT/bench_large_standing_h24.err
+python $R/bench.py --steps 20 --warmup 3 --workload long-stand --horizon 36 --no-cpu-all-cores --no-pipelined > $OUT/bench_large_stand_h36.json 2> $OUT/bench_large_stand_h36.err
 # the same standing workloads on the one-kernel path (before / after of the decoupled path in ONE profile set)
 for hh in 10 14 16; do
   QMPC_NO_SPLIT=1 python $R/bench.py --steps 200 --workload standing --horizon $hh --no-cpu-baseline --no-pipelined > $OUT/bench_standing_h${hh}_one_kernel.json 2>/dev/null
