@@ -733,11 +733,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // 1. pivot block (identity-padded) and pivot columns -> LDS
       if (tid < NB * NB) {
         const int pi = tid / NB, pj = tid % NB;
-        Pm[pi * PD + pj] = (pi < bsz && pj < bsz) ? ldA(k0 + pi, k0 + pj) : ((pi == pj) ? 1.0 : 0.0);
+        // (only the LOWER triangle of the sweep state is kept current: the state is symmetric, and the update streams the
+        //  matrix through L2 / HBM once per step -- that traffic is what this path costs)
+        Pm[pi * PD + pj] = (pi < bsz && pj < bsz) ? ldA(k0 + (pi > pj ? pi : pj), k0 + (pi > pj ? pj : pi)) : ((pi == pj) ? 1.0 : 0.0);
       }
       for (int e = tid; e < n * NB; e += NT) {
-        const int r = e / NB, kk = e % NB;
-        Cp[r * PD + kk] = (kk < bsz) ? ldA(r, k0 + kk) : 0.0;
+        const int r = e / NB, kk = e % NB, cc = k0 + kk;
+        Cp[r * PD + kk] = (kk < bsz) ? (r >= cc ? ldA(r, cc) : ldA(cc, r)) : 0.0;
       }
       __syncthreads();
       // 2. P = L L^T in place (the lower triangle of Pm becomes L).  NOT an explicit Gauss-Jordan inverse of the block: the
@@ -807,7 +809,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         double fr[NB];
 #pragma unroll
         for (int m = 0; m < NB; ++m) fr[m] = Fp[r * PD + m];
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j <= r; j += 64) {
           const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
           double v;
           if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
@@ -826,17 +828,22 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     if (__syncthreads_or(bad ? 1 : 0)) {
       if (tid == 0) S.status |= QMPC_DEV_ST_NOT_PD;
     }
-    // ---- A = -H^-1: x_u = A g; the work item gets +H^-1 (full matrix: the engine's lower-triangle reads find it all)
+    // ---- A = -H^-1 (lower triangle): the work item gets +H^-1, mirrored into the full matrix (the engine's reads find it
+    // whichever way they go); then x_u = -H^-1 g over full rows
+    for (int r = wv; r < n; r += NWV) {
+      for (int j = lane; j <= r; j += 64) {
+        const double v = -ldA(r, j);
+        A[(size_t)r * LDB + j] = v;
+        if (j < r) A[(size_t)j * LDB + r] = v;
+      }
+    }
+    __syncthreads();
     for (int r = wv; r < n; r += NWV) {
       double acc = 0.0;
-      for (int j = lane; j < n; j += 64) {
-        const double v = ldA(r, j);
-        acc = __builtin_fma(v, gl[j], acc);
-        A[(size_t)r * LDB + j] = -v;
-      }
+      for (int j = lane; j < n; j += 64) acc = __builtin_fma(-ldA(r, j), gl[j], acc);
 #pragma unroll
       for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
-      if (lane == 0) Fp[r] = acc;  // (x_u, parked beside g)
+      if (lane == 0) Fp[r] = acc;  // (x_u, parked where F was)
     }
     __syncthreads();
     constexpr int LDX = QMPC_BIG_LD;
