@@ -1185,12 +1185,14 @@ def test_class3_pool_slice_timeout_is_loud_and_safe(mpc_factory):
 
 
 @pytest.mark.parametrize("B,h,omni,stand,calm,split", [(192, 10, 0, 0.15, False, 1), (70, 16, 1, 0.3, True, 1), (33, 14, 0, 1.0, True, 1),
-                                                        (420, 10, 0, 0.5, False, 2), (150, 14, 1, 0.6, True, 2), (64, 24, 0, 0.0, True, 2)])
+                                                        (420, 10, 0, 0.5, False, 2), (150, 14, 1, 0.6, True, 2), (64, 24, 0, 0.0, True, 2),
+                                                        (24, 36, 0, 0.5, True, 2)])
 def test_fused_command_solve_is_bit_identical_to_the_three_calls(B, h, omni, stand, calm, split, mpc_factory):
     """qmpc_solve_commands (record generated in stage 0, state updated and forces rotated in the
     same launch) against qmpc_pack -> qmpc_solve -> qmpc_forces_to_body, across all size classes -- the last three cases
     through the decoupled path (command mode in the sweep kernel, state update and body-frame forces in the engine kernel),
-    one of them at a horizon of 24 segments."""
+    one of them at a horizon of 24 segments, the last at 36 with half of the robots standing (n_r = 432: command mode in the
+    large-problem producer and its seven-block engine)."""
     import torch
     cmd = W.make_commands(B, horizon=h, seed=300 + B, omni_mode=omni, stand_fraction=stand, calm=calm)
     m = mpc_factory(_pack_setup(cmd))
