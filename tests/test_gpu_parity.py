@@ -475,9 +475,10 @@ def test_large_problems_beyond_192_rows(h, gait, B, mpc_factory):
     # ("brake": all feet down, braking from 0.5 m/s -- 60+ active-set iterations: the engine's holders, its LDS pool and
     #  the overflow pool all hold events)
     b = W.make_standing(B, h) if gait == "brake" else W.make_long_horizon(B, h, gait)
-    if gait == "trot":  # a few robots of the 192-row class among them
+    if gait == "trot":  # a few robots of the 192-row class among them, and the x_drag terms of H and g (update_x_drag)
         small = W.make_long_horizon(B, h, "bound")
         b["gait"][B - 4:] = small["gait"][B - 4:]
+        b["x_drag"][:] = np.random.default_rng(3).normal(0, 0.6, B).astype(np.float32)
     nst = (b["gait"] != 0).sum(1)
     assert 3 * nst.max() > 192
     m = mpc_factory(b)
