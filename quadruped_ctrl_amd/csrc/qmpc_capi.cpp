@@ -200,7 +200,7 @@ int ensure_split(qmpc_ctx* c, int rb);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 13; }
+int qmpc_abi_version(void) { return 14; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
