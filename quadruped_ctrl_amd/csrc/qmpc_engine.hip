@@ -1365,7 +1365,7 @@ typedef EngineEntry<2, 1, 1, 4, 23, 42> Engine2;
 typedef EngineEntry<3, 2, 1, 4, 13, 25> Engine3;
 // engine of the large problems (192 < n_r <= 432: seven row blocks, 192 working slots, up to 144 stance foot-steps): 20 VGPRs
 // per event -- 3 holders x 6 in registers, 24 in LDS, the rest of the (long) histories in the overflow pool; one workgroup per CU
-typedef EngineEntry<7, 3, 3, 4, 2, 24> Engine7;
+typedef EngineEntry<7, 3, 3, 4, 6, 24> Engine7;
 static_assert(sizeof(ESmem<Engine3::C>) <= 80 * 1024 && sizeof(ESmem<Engine2::C>) <= 80 * 1024, "two engine workgroups per CU");
 
 }  // namespace

@@ -809,18 +809,32 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         double fr[NB];
 #pragma unroll
         for (int m = 0; m < NB; ++m) fr[m] = Fp[r * PD + m];
-        for (int j = lane; j <= r; j += 64) {
-          const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
-          double v;
-          if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
-          else if (jin) v = Fp[r * PD + (j - k0)];
-          else if (rin) v = Fp[j * PD + (r - k0)];
-          else {
-            v = ldA(r, j);
+        // (all of a row's loads are issued before the first is used: the triangle does not fit the L2 with 256 robots in
+        //  flight, a load is an HBM round trip, and one per 64 columns in a row would be seven in a row)
+        constexpr int NQ = (NMAX + 63) / 64;
+        double av[NQ];
 #pragma unroll
-            for (int m = 0; m < NB; ++m) v = __builtin_fma(-fr[m], Cp[j * PD + m], v);
+        for (int q = 0; q < NQ; ++q) {
+          const int j = lane + 64 * q;
+          const bool plain = j <= r && !rin && !((unsigned)(j - k0) < (unsigned)bsz);
+          av[q] = plain ? ldA(r, j) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int j = lane + 64 * q;
+          if (j <= r) {
+            const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
+            double v;
+            if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
+            else if (jin) v = Fp[r * PD + (j - k0)];
+            else if (rin) v = Fp[j * PD + (r - k0)];
+            else {
+              v = av[q];
+#pragma unroll
+              for (int m = 0; m < NB; ++m) v = __builtin_fma(-fr[m], Cp[j * PD + m], v);
+            }
+            A[(size_t)r * LDB + j] = v;
           }
-          A[(size_t)r * LDB + j] = v;
         }
       }
       __syncthreads();  // (every store of the step is in L2 before the next step reads)
