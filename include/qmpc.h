@@ -175,8 +175,9 @@ int qmpc_settings_jcqp(qmpc_handle h, int use_jcqp, int max_iter, double rho, do
  * n_r = 3 * (stance foot-steps in the horizon) <= 64 / 96 / 128 / 192; without a
  * hint every class that the horizon allows is launched (the unused ones exit
  * at once).  A caller that knows its contact tables (e.g. trot: 2 feet x h)
- * states the bound and the larger classes are skipped; a robot that exceeds
- * it is reported with QMPC_ST_WS_FULL instead of being solved.  0 = no hint. */
+ * states the bound and the larger classes are skipped (at horizons above 16: the large-problem stage behind the
+ * 192-row class -- three launches per call that normally find nothing to do -- when the bound is at most 64); a robot that
+ * exceeds it is reported with QMPC_ST_WS_FULL instead of being solved.  0 = no hint. */
 int qmpc_set_max_stance(qmpc_handle h, int max_stance_footsteps);
 /* Companion lower bound: when every robot has at least this many stance foot-steps, the
  * classes that are too small for all of them are not launched either (e.g. trot at

@@ -651,7 +651,9 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     k0 = 3;
     nclass_eff = 4;
   }
-  const bool long_h = h > QMPC_LONG_HORIZON;
+  // (the large-problem stage behind the 192-row class: three more launches per call, normally empty -- skipped when the
+  //  caller's size hint, qmpc_set_max_stance, rules such robots out; a violator is reported like any other)
+  const bool long_h = h > QMPC_LONG_HORIZON && !(c->max_stance > 0 && 3 * c->max_stance <= 192);
   for (int k = k0; k < nclass_eff; ++k) {
     P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
     P.count = k > k0 ? cnt + (k - 1) : nullptr;
