@@ -683,6 +683,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     const int wv = tid >> 6;
     constexpr int NWV = NT / 64;
     const double dm2 = x_drag * inv_m * inv_m;
+
     // ---- g (one variable per thread: n <= 432 < 768), as in stage 2
     double gmine = 0.0;
     if (tid < n) {
@@ -765,15 +766,20 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       }
       // 2b. L^-1 (one column per thread, forward substitution) and P^-1 = L^-T L^-1 for the pivot block itself
       if (tid < NB) {
+        // (compile-time indices only -- StaticFor, not loops whose bounds depend on an outer index: those were left rolled
+        //  and the little vectors went to scratch, 1.6 KB per lane)
         double x[NB];
-#pragma unroll
-        for (int i2 = 0; i2 < NB; ++i2) {
+        StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i2 = decltype(ic)::value;
           double acc = (i2 == tid) ? 1.0 : 0.0;
-#pragma unroll
-          for (int m = 0; m < i2; ++m) acc = __builtin_fma(-Pm[i2 * PD + m], (m >= tid) ? x[m] : 0.0, acc);
+          StaticFor<0, i2>::run([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            acc = __builtin_fma(-Pm[i2 * PD + m], (m >= tid) ? x[m] : 0.0, acc);
+          });
           x[i2] = (i2 >= tid) ? acc / Pm[i2 * PD + i2] : 0.0;
           Qm[i2 * PD + tid] = x[i2];
-        }
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
       __syncthreads();
       if (tid < NB * NB) {
@@ -786,54 +792,70 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // 3. F = C P^-1 row by row through the factor: L y = C_r^T, L^T f = y
       if (tid < n) {
         double y[NB];
-#pragma unroll
-        for (int i2 = 0; i2 < NB; ++i2) {
+        StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i2 = decltype(ic)::value;
           double acc = Cp[tid * PD + i2];
-#pragma unroll
-          for (int m = 0; m < i2; ++m) acc = __builtin_fma(-Pm[i2 * PD + m], y[m], acc);
+          StaticFor<0, i2>::run([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            acc = __builtin_fma(-Pm[i2 * PD + m], y[m], acc);
+          });
           y[i2] = acc / Pm[i2 * PD + i2];
-        }
-#pragma unroll
-        for (int i2 = NB - 1; i2 >= 0; --i2) {
+          __builtin_amdgcn_sched_barrier(0);  // (row by row: hoisted, the 136 loads of L spill)
+        });
+        StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i2 = NB - 1 - decltype(ic)::value;
           double acc = y[i2];
-#pragma unroll
-          for (int m = i2 + 1; m < NB; ++m) acc = __builtin_fma(-Pm[m * PD + i2], y[m], acc);
+          StaticFor<i2 + 1, NB>::run([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            acc = __builtin_fma(-Pm[m * PD + i2], y[m], acc);
+          });
           y[i2] = acc / Pm[i2 * PD + i2];
           Fp[tid * PD + i2] = y[i2];
-        }
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
       __syncthreads();
-      // 4. the sweep step: off-block A -= F C^T ; pivot columns / rows <- F ; pivot block <- -P^-1
-      for (int r = wv; r < n; r += NWV) {
-        const bool rin = (unsigned)(r - k0) < (unsigned)bsz;
-        double fr[NB];
-#pragma unroll
-        for (int m = 0; m < NB; ++m) fr[m] = Fp[r * PD + m];
-        // (all of a row's loads are issued before the first is used: the triangle does not fit the L2 with 256 robots in
-        //  flight, a load is an HBM round trip, and one per 64 columns in a row would be seven in a row)
+      // 4. the sweep step: off-block A -= F C^T ; pivot columns / rows <- F ; pivot block <- -P^-1.  The triangle does not
+      // fit the L2 with 256 robots in flight: a load is an HBM round trip (5 - 7 k cycles), and a wave has 36 rows to do.
+      // So all of a row's loads are issued together, and the NEXT row's before this row is computed
+      {
         constexpr int NQ = (NMAX + 63) / 64;
-        double av[NQ];
+        auto fetch = [&](int r, double (&dst)[NQ]) __attribute__((always_inline)) {
+          const bool rin = (unsigned)(r - k0) < (unsigned)bsz;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int j = lane + 64 * q;
-          const bool plain = j <= r && !rin && !((unsigned)(j - k0) < (unsigned)bsz);
-          av[q] = plain ? ldA(r, j) : 0.0;
-        }
+          for (int q = 0; q < NQ; ++q) {
+            const int j = lane + 64 * q;
+            const bool plain = r < n && j <= r && !rin && !((unsigned)(j - k0) < (unsigned)bsz);
+            dst[q] = plain ? ldA(r, j) : 0.0;
+          }
+        };
+        double av[NQ], an[NQ];
+        fetch(wv, an);
+#pragma unroll 1
+        for (int r = wv; r < n; r += NWV) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int j = lane + 64 * q;
-          if (j <= r) {
-            const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
-            double v;
-            if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
-            else if (jin) v = Fp[r * PD + (j - k0)];
-            else if (rin) v = Fp[j * PD + (r - k0)];
-            else {
-              v = av[q];
+          for (int q = 0; q < NQ; ++q) av[q] = an[q];
+          fetch(r + NWV, an);
+          const bool rin = (unsigned)(r - k0) < (unsigned)bsz;
+          double fr[NB];
 #pragma unroll
-              for (int m = 0; m < NB; ++m) v = __builtin_fma(-fr[m], Cp[j * PD + m], v);
+          for (int m = 0; m < NB; ++m) fr[m] = Fp[r * PD + m];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int j = lane + 64 * q;
+            if (j <= r) {
+              const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
+              double v;
+              if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
+              else if (jin) v = Fp[r * PD + (j - k0)];
+              else if (rin) v = Fp[j * PD + (r - k0)];
+              else {
+                v = av[q];
+#pragma unroll
+                for (int m = 0; m < NB; ++m) v = __builtin_fma(-fr[m], Cp[j * PD + m], v);
+              }
+              A[(size_t)r * LDB + j] = v;
             }
-            A[(size_t)r * LDB + j] = v;
           }
         }
       }
