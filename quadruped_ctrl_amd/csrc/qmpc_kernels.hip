@@ -815,46 +815,53 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         });
       }
       __syncthreads();
-      // 4. the sweep step: off-block A -= F C^T ; pivot columns / rows <- F ; pivot block <- -P^-1.  The triangle does not
-      // fit the L2 with 256 robots in flight: a load is an HBM round trip (5 - 7 k cycles), and a wave has 36 rows to do.
-      // So all of a row's loads are issued together, and the NEXT row's before this row is computed
+      // 4. the sweep step on the lower triangle.  (a) The pivot columns / rows <- F and the pivot block <- -P^-1: n x 16
+      // entries, one thread each.  (b) Everything else, A <- A - F C^T, IS a GEMM (rank 16 per step) and runs on the matrix
+      // cores: 16 x 16 tiles of the triangle dealt to the waves, four v_mfma_f64_16x16x4 per tile -- accumulator lane
+      // (lc = lane & 15, rq = lane >> 4), register g = element (row rq + 4 g, column lc); A operand = -F[row lc][k = rq],
+      // B operand = C[column lc][k = rq] -- i.e. 8 LDS reads and 4 matrix instructions per lane and tile where the vector
+      // version had 64 reads and 64 multiply-adds
+      for (int e = tid; e < n * NB; e += NT) {
+        const int r = e / NB, m = e % NB;
+        if (m < bsz) {
+          if (r >= k0 + bsz) A[(size_t)r * LDB + k0 + m] = Fp[r * PD + m];
+          else if (r < k0) A[(size_t)(k0 + m) * LDB + r] = Fp[r * PD + m];
+          else if (m <= r - k0) A[(size_t)r * LDB + k0 + m] = -Rm[(r - k0) * PD + m];
+        }
+      }
       {
-        constexpr int NQ = (NMAX + 63) / 64;
-        auto fetch = [&](int r, double (&dst)[NQ]) __attribute__((always_inline)) {
-          const bool rin = (unsigned)(r - k0) < (unsigned)bsz;
-#pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int j = lane + 64 * q;
-            const bool plain = r < n && j <= r && !rin && !((unsigned)(j - k0) < (unsigned)bsz);
-            dst[q] = plain ? ldA(r, j) : 0.0;
-          }
-        };
-        double av[NQ], an[NQ];
-        fetch(wv, an);
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int ntl = (n + 15) >> 4, kb = k0 >> 4;
+        const int lc = lane & 15, rq = lane >> 4;
+        int cnt = 0;
 #pragma unroll 1
-        for (int r = wv; r < n; r += NWV) {
+        for (int ti = 0; ti < ntl; ++ti) {
+          if (ti == kb) continue;
+#pragma unroll 1
+          for (int tj = 0; tj <= ti; ++tj) {
+            if (tj == kb) continue;
+            const bool mine = (cnt % NWV) == wv;
+            cnt += 1;
+            if (!mine) continue;  // (wave-uniform)
+            const int R0 = 16 * ti, J0 = 16 * tj;
+            const int col = J0 + lc;
+            v4d acc;
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) av[q] = an[q];
-          fetch(r + NWV, an);
-          const bool rin = (unsigned)(r - k0) < (unsigned)bsz;
-          double fr[NB];
+            for (int g = 0; g < 4; ++g) {
+              const int row = R0 + rq + 4 * g;
+              acc[g] = (row < n && col < n) ? ldA(row, col) : 0.0;
+            }
+            const int fr_row = R0 + lc;
 #pragma unroll
-          for (int m = 0; m < NB; ++m) fr[m] = Fp[r * PD + m];
+            for (int kc = 0; kc < 4; ++kc) {
+              const double aop = (fr_row < n) ? -Fp[fr_row * PD + 4 * kc + rq] : 0.0;
+              const double bop = (col < n) ? Cp[col * PD + 4 * kc + rq] : 0.0;
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+            }
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int j = lane + 64 * q;
-            if (j <= r) {
-              const bool jin = (unsigned)(j - k0) < (unsigned)bsz;
-              double v;
-              if (rin && jin) v = -Rm[(r - k0) * PD + (j - k0)];
-              else if (jin) v = Fp[r * PD + (j - k0)];
-              else if (rin) v = Fp[j * PD + (r - k0)];
-              else {
-                v = av[q];
-#pragma unroll
-                for (int m = 0; m < NB; ++m) v = __builtin_fma(-fr[m], Cp[j * PD + m], v);
-              }
-              A[(size_t)r * LDB + j] = v;
+            for (int g = 0; g < 4; ++g) {
+              const int row = R0 + rq + 4 * g;
+              if (row < n && col <= row) A[(size_t)row * LDB + col] = acc[g];
             }
           }
         }
