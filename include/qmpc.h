@@ -54,7 +54,7 @@ extern "C" {
                                stance foot-steps in the horizon, n_r = 3 x stance foot-steps <= 192: trot up to 32
                                segments, gaits with a duty factor <= 0.44 up to 36) and, beyond that, by the
                                LARGE-PROBLEM path (n_r up to 432 = all four feet down for 36 segments: the Hessian in
-                               global memory, a block sweep, a seven-block engine; 8e4 .. 4e5 QP solves/s instead of ~1e6 --
+                               global memory, a block sweep, a seven-block engine; 1e5 .. 4e5 QP solves/s instead of ~1e6 --
                                coverage of the interface, not a fast path; 1.6 MiB of device memory per robot of the
                                handle's max_batch, allocated on the first call at such a horizon) */
 #define QMPC_LONG_HORIZON 16 /* horizons above this take the long-horizon routes described above */

@@ -725,8 +725,21 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     double* const Qm = Pm + NB * PD;                      // L^-1
     double* const Rm = Qm + NB * PD;                      // P^-1 = L^-T L^-1
     double* const gl = Rm + NB * PD;                      // g [NMAX]
-    static_assert(sizeof(double) * (2 * NMAX * PD + 3 * NB * PD + NMAX) <= sizeof(S.u), "scratch of the block sweep");
+    constexpr int NTLMAX = (NMAX + 15) / 16, TLW = (NTLMAX * (NTLMAX + 1) / 2 + NWV - 1) / NWV;
+    unsigned short* const tl = reinterpret_cast<unsigned short*>(gl + NMAX);  // the waves' tile lists [NWV][TLW]
+    static_assert(sizeof(double) * (2 * NMAX * PD + 3 * NB * PD + NMAX) + 2 * NWV * TLW <= sizeof(S.u), "scratch of the block sweep");
     if (tid < NMAX) gl[tid] = gmine;
+    // the 16 x 16 tiles (ti, tj <= ti) of the lower triangle, dealt round-robin to the waves ONCE per robot: tile p -> wave
+    // p mod NWV, position p / NWV (every step walks the same lists and skips the tiles of its pivot row / column block)
+    {
+      const int ntl0 = (n + 15) >> 4, ntiles = ntl0 * (ntl0 + 1) / 2;
+      for (int pq = tid; pq < ntiles; pq += NT) {
+        int ti0 = (int)((__builtin_sqrtf(8.f * (float)pq + 1.f) - 1.f) * 0.5f);
+        while (ti0 * (ti0 + 1) / 2 > pq) --ti0;
+        while ((ti0 + 1) * (ti0 + 2) / 2 <= pq) ++ti0;
+        tl[(pq % NWV) * TLW + pq / NWV] = (unsigned short)((ti0 << 8) | (pq - ti0 * (ti0 + 1) / 2));
+      }
+    }
     bool bad = false;
 #pragma unroll 1
     for (int k0 = 0; k0 < n; k0 += NB) {
@@ -833,37 +846,54 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         typedef double v4d __attribute__((ext_vector_type(4)));
         const int ntl = (n + 15) >> 4, kb = k0 >> 4;
         const int lc = lane & 15, rq = lane >> 4;
-        int cnt = 0;
-#pragma unroll 1
-        for (int ti = 0; ti < ntl; ++ti) {
-          if (ti == kb) continue;
-#pragma unroll 1
-          for (int tj = 0; tj <= ti; ++tj) {
-            if (tj == kb) continue;
-            const bool mine = (cnt % NWV) == wv;
-            cnt += 1;
-            if (!mine) continue;  // (wave-uniform)
-            const int R0 = 16 * ti, J0 = 16 * tj;
-            const int col = J0 + lc;
-            v4d acc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int row = R0 + rq + 4 * g;
-              acc[g] = (row < n && col < n) ? ldA(row, col) : 0.0;
-            }
-            const int fr_row = R0 + lc;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-              const double aop = (fr_row < n) ? -Fp[fr_row * PD + 4 * kc + rq] : 0.0;
-              const double bop = (col < n) ? Cp[col * PD + 4 * kc + rq] : 0.0;
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int row = R0 + rq + 4 * g;
-              if (row < n && col <= row) A[(size_t)row * LDB + col] = acc[g];
-            }
+        const int ntiles = ntl * (ntl + 1) / 2, cntw = (ntiles > wv) ? (ntiles - wv + NWV - 1) / NWV : 0;
+        const unsigned short* const mytl = tl + wv * TLW;
+        int idx = 0;
+        // the next tile of this wave outside the pivot row / column block (false: none left)
+        auto next_tile = [&](int& ti, int& tj) __attribute__((always_inline)) {
+          while (idx < cntw) {
+            const int e = mytl[idx++];
+            ti = e >> 8;
+            tj = e & 255;
+            if (ti != kb && tj != kb) return true;
           }
+          return false;
+        };
+        auto fetch = [&](int ti, int tj) __attribute__((always_inline)) {
+          v4d acc;
+          const int col = 16 * tj + lc;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * ti + rq + 4 * g;
+            acc[g] = (row < n && col < n) ? ldA(row, col) : 0.0;
+          }
+          return acc;
+        };
+        // (the NEXT tile's entries are requested before the current tile is multiplied: a load is an HBM round trip)
+        int ti = 0, tj = 0, ni = 0, nj = 0;
+        bool have = next_tile(ti, tj);
+        v4d acc_n = {0.0, 0.0, 0.0, 0.0};
+        if (have) acc_n = fetch(ti, tj);
+#pragma unroll 1
+        while (have) {
+          v4d acc = acc_n;
+          const bool more = next_tile(ni, nj);
+          if (more) acc_n = fetch(ni, nj);
+          const int R0 = 16 * ti, col = 16 * tj + lc, fr_row = R0 + lc;
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            const double aop = (fr_row < n) ? -Fp[fr_row * PD + 4 * kc + rq] : 0.0;
+            const double bop = (col < n) ? Cp[col * PD + 4 * kc + rq] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = R0 + rq + 4 * g;
+            if (row < n && col <= row) A[(size_t)row * LDB + col] = acc[g];
+          }
+          ti = ni;
+          tj = nj;
+          have = more;
         }
       }
       __syncthreads();  // (every store of the step is in L2 before the next step reads)
