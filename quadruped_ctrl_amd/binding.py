@@ -79,6 +79,13 @@ def load_library():
     failure when absent -- the product has no other compute path."""
     global _lib
     if _lib is None:
+        # PyTorch ships its own copy of the HIP runtime: it has to be the one this process loads FIRST.  Loaded after
+        # libqmpc.so (which would pull /opt/rocm's), the process ends up with two runtimes and the kernels registered with
+        # the wrong one -- qmpc_create then fails with QMPC_ERR_DEVICE (build() followed by smoke() in one process did)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP extension first "
