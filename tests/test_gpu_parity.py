@@ -712,6 +712,18 @@ def test_smoke_entry():
     g.smoke()
 
 
+def test_build_then_smoke_in_one_fresh_process():
+    """build() loads libqmpc.so BEFORE anything has imported torch; the binding has to bring PyTorch's HIP runtime in
+    first or the process ends up with two runtimes and qmpc_create fails."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "smoke: 64 robots" in r.stdout
+
+
 def test_size_hint(mpc_factory):
     """qmpc_set_max_stance: a correct bound changes nothing; robots above the
     bound are reported (QMPC_ST_WS_FULL), not silently mis-solved."""
