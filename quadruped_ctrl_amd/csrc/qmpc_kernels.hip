@@ -92,6 +92,12 @@ __device__ __forceinline__ void fmac16_rowbcast(double (&a)[16], double c, doubl
       : "v"(c), "v"(u));
 }
 
+// acc += c[lane N of this lane's row of 16] * u (one DP-ALU DPP fmac; N a compile-time lane)
+template <int N>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double c, double u) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(u), "n"(N));
+}
+
 // the same for four accumulators a[J0 .. J0+3] (lets the producing wave of the
 // sweep interleave its pivot arithmetic with the update)
 template <int J0>
@@ -666,6 +672,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   __syncthreads();  // ---- barrier 2
   QMPC_TICK(2);
 
+#ifdef QMPC_BIG_STAMP  // (profiling build, tools/big_phase.py: shader-clock stamps of block step QMPC_BIG_STAMP and of the stages around the sweep)
+#define QMPC_BIG_TICK(k) do { if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); } while (0)
+#define QMPC_BIG_STEP_TICK(k) do { if (dbg_clk && tid == 0 && k0 == NB * QMPC_BIG_STAMP) dbg_clk[(k)] = clock64(); } while (0)
+#else
+#define QMPC_BIG_TICK(k) do { } while (0)
+#define QMPC_BIG_STEP_TICK(k) do { } while (0)
+#endif
   if constexpr (BIG) {
     // ------------------------------------------------------------ the large problems (192 < n_r <= 432)
     // The reference's interface takes up to K_MAX_GAIT_SEGMENTS = 36 segments: all four feet down at 36 segments is
@@ -677,13 +690,16 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     constexpr int LDB = QMPC_BIG_LD, NB = 16, PD = NB + 1, NMAX = 3 * Smem<RB>::SLOTS;
     const int item = S.evslot;
     GlobalF64* const A = (GlobalF64*)P.wk_hinv + (size_t)item * ((size_t)LDB * LDB);
-    auto ldA = [&](int r, int cidx) __attribute__((always_inline)) {  // (past the L1: other waves wrote it)
-      return __hip_atomic_load(A + (size_t)r * LDB + cidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the item is this workgroup's alone until the kernel ends: workgroup scope -- the L2 may serve it; at agent scope every
+    //  load went out to the fabric)
+    auto ldA = [&](int r, int cidx) __attribute__((always_inline)) {
+      return __hip_atomic_load(A + (size_t)r * LDB + cidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     const int wv = tid >> 6;
     constexpr int NWV = NT / 64;
     const double dm2 = x_drag * inv_m * inv_m;
 
+    QMPC_BIG_TICK(8);
     // ---- g (one variable per thread: n <= 432 < 768), as in stage 2
     double gmine = 0.0;
     if (tid < n) {
@@ -719,6 +735,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       }
     }
     __syncthreads();  // (the tables are dead: the union becomes scratch; the rows of H are in L2)
+    QMPC_BIG_TICK(9);
     double* const Cp = reinterpret_cast<double*>(&S.u);  // C[NMAX][PD]: the pivot columns
     double* const Fp = Cp + NMAX * PD;                    // F[NMAX][PD] = C P^-1
     double* const Pm = Fp + NMAX * PD;                    // the pivot block, then its Cholesky factor L [NB][PD]
@@ -744,6 +761,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #pragma unroll 1
     for (int k0 = 0; k0 < n; k0 += NB) {
       const int bsz = (n - k0 < NB) ? n - k0 : NB;
+      QMPC_BIG_STEP_TICK(0);
       // 1. pivot block (identity-padded) and pivot columns -> LDS
       if (tid < NB * NB) {
         const int pi = tid / NB, pj = tid % NB;
@@ -756,78 +774,104 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         Cp[r * PD + kk] = (kk < bsz) ? (r >= cc ? ldA(r, cc) : ldA(cc, r)) : 0.0;
       }
       __syncthreads();
+      QMPC_BIG_STEP_TICK(1);
       // 2. P = L L^T in place (the lower triangle of Pm becomes L).  NOT an explicit Gauss-Jordan inverse of the block: the
       // four feet of a step push the body almost identically, a 16 x 16 block of the sweep state has eigenvalues down to
       // the regulariser alpha, and F = C P^-1 through an unpivoted explicit inverse loses the digits the whole sweep
       // needs (measured on all feet down at 36 segments: H^-1 to 1e-1 -- through the factor: 4e-12; oracle-side study)
-#pragma unroll 1
-      for (int pp = 0; pp < NB; ++pp) {
-        double vnew = 0.0;
-        const int pi = tid / NB, pj = tid % NB;
-        if (tid < NB * NB) {
-          const double d = Pm[pp * PD + pp], vo = Pm[pi * PD + pj];
-          bad |= !(d > 0.0);
-          const double lpp = __builtin_sqrt(d);
-          vnew = vo;
-          if (pj == pp && pi == pp) vnew = lpp;
-          else if (pj == pp && pi > pp) vnew = vo / lpp;
-          else if (pi > pp && pj > pp) vnew = vo - (Pm[pi * PD + pp] / lpp) * (Pm[pj * PD + pp] / lpp);
-        }
-        __syncthreads();
-        if (tid < NB * NB) Pm[pi * PD + pj] = vnew;
-        __syncthreads();
-      }
-      // 2b. L^-1 (one column per thread, forward substitution) and P^-1 = L^-T L^-1 for the pivot block itself
-      if (tid < NB) {
-        // (compile-time indices only -- StaticFor, not loops whose bounds depend on an outer index: those were left rolled
-        //  and the little vectors went to scratch, 1.6 KB per lane)
-        double x[NB];
-        StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
-          constexpr int i2 = decltype(ic)::value;
-          double acc = (i2 == tid) ? 1.0 : 0.0;
-          StaticFor<0, i2>::run([&](auto mc) __attribute__((always_inline)) {
-            constexpr int m = decltype(mc)::value;
-            acc = __builtin_fma(-Pm[i2 * PD + m], (m >= tid) ? x[m] : 0.0, acc);
-          });
-          x[i2] = (i2 >= tid) ? acc / Pm[i2 * PD + i2] : 0.0;
-          Qm[i2 * PD + tid] = x[i2];
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-      __syncthreads();
-      if (tid < NB * NB) {
-        const int pi = tid / NB, pj = tid % NB;
-        double acc = 0.0;
+      // ONE wave, in registers: lane i (of every 16) holds row i of the block; a column's entries reach the other rows
+      // through DPP broadcasts (row_newbcast), 1 / sqrt(d) is a seed and two Newton steps -- straight-line code, ~5 k
+      // cycles with L^-1, where 256 threads with two workgroup barriers per column took 13.5 k and one wave going through
+      // LDS 15 k (a dozen predicated LDS accesses per column, each its own branch)
+      if (wv == 0) {
+        const int i16 = lane & 15;
+        double pr[NB];
 #pragma unroll
-        for (int m = 0; m < NB; ++m) acc = __builtin_fma(Qm[m * PD + pi], Qm[m * PD + pj], acc);
-        Rm[pi * PD + pj] = acc;
-      }
-      // 3. F = C P^-1 row by row through the factor: L y = C_r^T, L^T f = y
-      if (tid < n) {
-        double y[NB];
-        StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
-          constexpr int i2 = decltype(ic)::value;
-          double acc = Cp[tid * PD + i2];
-          StaticFor<0, i2>::run([&](auto mc) __attribute__((always_inline)) {
-            constexpr int m = decltype(mc)::value;
-            acc = __builtin_fma(-Pm[i2 * PD + m], y[m], acc);
-          });
-          y[i2] = acc / Pm[i2 * PD + i2];
-          __builtin_amdgcn_sched_barrier(0);  // (row by row: hoisted, the 136 loads of L spill)
+        for (int j = 0; j < NB; ++j) pr[j] = Pm[i16 * PD + j];
+        StaticFor<0, NB>::run([&](auto ppc) __attribute__((always_inline)) {
+          constexpr int pp = decltype(ppc)::value;
+          double d = 0.0;
+          fmac_rowbcast<pp>(d, pr[pp], 1.0);
+          bad |= !(d > 0.0);
+          double rl = __builtin_amdgcn_rsq(d);
+          double e = __builtin_fma(-d * rl, rl, 1.0);
+          rl = __builtin_fma(0.5 * rl, e, rl);
+          e = __builtin_fma(-d * rl, rl, 1.0);
+          rl = __builtin_fma(0.5 * rl, e, rl);
+          const double l = pr[pp] * rl;  // L_ip; row pp keeps 1 / L_pp instead (all that is needed of the diagonal)
+          pr[pp] = (i16 == pp) ? rl : l;
+          const double cl = (i16 > pp) ? l : 0.0;
+          fmac16_rowbcast(pr, cl, -cl);  // P_ij -= L_ip L_jp for i, j > pp (columns <= pp: the broadcast value is 0)
         });
-        StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
-          constexpr int i2 = NB - 1 - decltype(ic)::value;
-          double acc = y[i2];
-          StaticFor<i2 + 1, NB>::run([&](auto mc) __attribute__((always_inline)) {
-            constexpr int m = decltype(mc)::value;
-            acc = __builtin_fma(-Pm[m * PD + i2], y[m], acc);
+        if (lane < NB) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) Pm[lane * PD + j] = pr[j];  // (row i: L_i0 .. L_i,i-1, 1 / L_ii)
+        }
+        __builtin_amdgcn_wave_barrier();
+        QMPC_BIG_STEP_TICK(7);
+        // 2b. L^-1, column c on lane c (of every 16): forward substitution, the entries of L broadcast from LDS row by row
+        // (entries above the diagonal of L^-1 come out as exact zeros: no predicates; a scheduling barrier per row, or the
+        //  136 loads are hoisted to the top and spill)
+        {
+          double x[NB];
+          StaticFor<0, NB>::run([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i2 = decltype(ic)::value;
+            double acc = (i2 == i16) ? 1.0 : 0.0;
+            StaticFor<0, i2>::run([&](auto mc) __attribute__((always_inline)) {
+              constexpr int m = decltype(mc)::value;
+              acc = __builtin_fma(-Pm[i2 * PD + m], x[m], acc);
+            });
+            x[i2] = acc * Pm[i2 * PD + i2];
+            if (lane < NB) Qm[i2 * PD + lane] = x[i2];
+            __builtin_amdgcn_sched_barrier(0);
           });
-          y[i2] = acc / Pm[i2 * PD + i2];
-          Fp[tid * PD + i2] = y[i2];
-          __builtin_amdgcn_sched_barrier(0);
-        });
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+          // P^-1 = L^-T L^-1: one 16 x 16 x 16 product, both operands the same LDS entry (A = Li^T[row lc][k], B = Li[k][col lc])
+          typedef double v4d __attribute__((ext_vector_type(4)));
+          const int lc = lane & 15, rq = lane >> 4;
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            const double v = Qm[(4 * kc + rq) * PD + lc];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Rm[(rq + 4 * g) * PD + lc] = acc[g];
+        }
       }
       __syncthreads();
+      QMPC_BIG_STEP_TICK(2);
+      // 3. F = C P^-1 = (C L^-T) L^-1: two products with the explicit inverse of the FACTOR (as accurate as the two
+      // substitutions per row they replace -- oracle-side study: 5e-12 either way at n_r = 432, where C (L^-T L^-1) as one
+      // product loses four digits --, and on the matrix cores: 16 rows per wave at a time, the intermediate through LDS)
+      {
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int lc = lane & 15, rq = lane >> 4;
+        const int ntl = (n + 15) >> 4;
+        for (int t = wv; t < ntl; t += NWV) {
+          const int R0 = 16 * t;
+          v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            const double aop = (R0 + lc < n) ? Cp[(R0 + lc) * PD + 4 * kc + rq] : 0.0;
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Qm[lc * PD + 4 * kc + rq], y, 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Fp[(R0 + rq + 4 * g) * PD + lc] = y[g];
+          __builtin_amdgcn_wave_barrier();
+          v4d f = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc)
+            f = __builtin_amdgcn_mfma_f64_16x16x4f64(Fp[(R0 + lc) * PD + 4 * kc + rq], Qm[(4 * kc + rq) * PD + lc], f, 0, 0, 0);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Fp[(R0 + rq + 4 * g) * PD + lc] = f[g];
+        }
+      }
+      __syncthreads();
+      QMPC_BIG_STEP_TICK(3);
       // 4. the sweep step on the lower triangle.  (a) The pivot columns / rows <- F and the pivot block <- -P^-1: n x 16
       // entries, one thread each.  (b) Everything else, A <- A - F C^T, IS a GEMM (rank 16 per step) and runs on the matrix
       // cores: 16 x 16 tiles of the triangle dealt to the waves, four v_mfma_f64_16x16x4 per tile -- accumulator lane
@@ -896,29 +940,87 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           have = more;
         }
       }
+      QMPC_BIG_STEP_TICK(4);
       __syncthreads();  // (every store of the step is in L2 before the next step reads)
+      QMPC_BIG_STEP_TICK(5);
     }
     if (__syncthreads_or(bad ? 1 : 0)) {
       if (tid == 0) S.status |= QMPC_DEV_ST_NOT_PD;
     }
+    QMPC_BIG_TICK(10);
     // ---- A = -H^-1 (lower triangle): the work item gets +H^-1, mirrored into the full matrix (the engine's reads find it
     // whichever way they go); then x_u = -H^-1 g over full rows
-    for (int r = wv; r < n; r += NWV) {
-      for (int j = lane; j <= r; j += 64) {
-        const double v = -ldA(r, j);
-        A[(size_t)r * LDB + j] = v;
-        if (j < r) A[(size_t)j * LDB + r] = v;
+    // Tile by tile (the waves' lists again), two tiles per trip with every load issued before the first use; the mirrored
+    // tile goes through a 16 x 17 LDS patch of the wave so that both copies leave as whole 128-byte rows (written entry
+    // by entry down a column -- 64 partial lines per store -- this pass took 0.45 M of 5.2 M cycles at n_r = 432)
+    constexpr int NQ = (NMAX + 63) / 64;
+    {
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      const int lc = lane & 15, rq = lane >> 4;
+      const int ntl = (n + 15) >> 4, ntiles = ntl * (ntl + 1) / 2, cntw = (ntiles > wv) ? (ntiles - wv + NWV - 1) / NWV : 0;
+      const unsigned short* const mytl = tl + wv * TLW;
+      double* const T = Cp + wv * (2 * 16 * PD);  // (the pivot columns are dead)
+      for (int i0 = 0; i0 < cntw; i0 += 2) {
+        v4d v[2];
+        int ti[2], tj[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int e = (i0 + w < cntw) ? mytl[i0 + w] : 0xffff;
+          ti[w] = e >> 8;
+          tj[w] = e & 255;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * ti[w] + rq + 4 * g, col = 16 * tj[w] + lc;
+            v[w][g] = (row < n && col <= row) ? -ldA(row, col) : 0.0;
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * ti[w] + rq + 4 * g, col = 16 * tj[w] + lc;
+            if (row < n && col <= row) A[(size_t)row * LDB + col] = v[w][g];
+            T[w * 16 * PD + (rq + 4 * g) * PD + lc] = v[w][g];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            // entry (row', col') of the mirrored tile = entry (col', row') of the tile
+            const int row = 16 * tj[w] + rq + 4 * g, col = 16 * ti[w] + lc;
+            if (col < n && row < col) A[(size_t)row * LDB + col] = T[w * 16 * PD + lc * PD + rq + 4 * g];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
     __syncthreads();
-    for (int r = wv; r < n; r += NWV) {
-      double acc = 0.0;
-      for (int j = lane; j < n; j += 64) acc = __builtin_fma(-ldA(r, j), gl[j], acc);
+    QMPC_BIG_TICK(14);
+    for (int r = wv; r < n; r += 2 * NWV) {
+      double v[2][NQ], gq[NQ];
 #pragma unroll
-      for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
-      if (lane == 0) Fp[r] = acc;  // (x_u, parked where F was)
+      for (int q = 0; q < NQ; ++q) gq[q] = (lane + 64 * q < n) ? gl[lane + 64 * q] : 0.0;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int rr = r + w * NWV, j = lane + 64 * q;
+          v[w][q] = (rr < n && j < n) ? ldA(rr, j) : 0.0;
+        }
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc = __builtin_fma(-v[w][q], gq[q], acc);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
+        if (lane == 0 && r + w * NWV < n) Fp[r + w * NWV] = acc;  // (x_u, parked where F was)
+      }
     }
     __syncthreads();
+    QMPC_BIG_TICK(15);
     constexpr int LDX = QMPC_BIG_LD;
     if (tid < LDX) P.wk_xu[(size_t)item * LDX + tid] = (tid < n) ? Fp[tid] : 0.0;
     QmpcWorkHdr* const hd = P.wk_hdr + item;

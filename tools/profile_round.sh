@@ -31,6 +31,15 @@ python $R/bench.py --steps 50 --workload long-bound --horizon 36 --no-cpu-all-co
 python $R/bench.py --steps 30 --warmup 3 --workload long-trot --horizon 36 --no-cpu-all-cores --no-pipelined > $OUT/bench_large_trot_h36.json 2> $OUT/bench_large_trot_h36.err
 python $R/bench.py --steps 20 --warmup 3 --workload standing --horizon 24 --no-cpu-all-cores --no-pipelined > $OUT/bench_large_standing_h24.json 2> $OUT/bench_large_standing_h24.err
 python $R/bench.py --steps 20 --warmup 3 --workload long-stand --horizon 36 --no-cpu-all-cores --no-pipelined > $OUT/bench_large_stand_h36.json 2> $OUT/bench_large_stand_h36.err
+for w in "large_trot_h36 long-trot 36 30" "large_stand_h36 long-stand 36 20"; do
+  set -- $w
+  rocprofv3 --kernel-trace --stats -d $OUT/stats_$1 -o s --output-format csv -- \
+      python $R/bench.py --steps $4 --warmup 3 --workload $2 --horizon $3 --no-cpu-baseline --no-pipelined > $OUT/stats_$1.log 2>&1
+  find $OUT/stats_$1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$1.csv \;
+  rm -rf $OUT/stats_$1
+done
+python $R/tools/stress_large.py 160 2>/dev/null | grep -v amdgpu > $OUT/stress_parity_large.txt
+QMPC_STRESS_SPLIT=1 python $R/tools/stress_parity.py 400 2>/dev/null | grep -v amdgpu > $OUT/stress_parity_decoupled.txt
 # the same standing workloads on the one-kernel path (before / after of the decoupled path in ONE profile set)
 for hh in 10 14 16; do
   QMPC_NO_SPLIT=1 python $R/bench.py --steps 200 --workload standing --horizon $hh --no-cpu-baseline --no-pipelined > $OUT/bench_standing_h${hh}_one_kernel.json 2>/dev/null
