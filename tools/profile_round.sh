@@ -2,7 +2,8 @@
 # One round's measurement set, run on the GPU box:  gpurun -- 'bash tools/profile_round.sh r02_a'
 # For configs[1] and the standing / horizon-16 workloads (size classes 1, 2, 3, 4):
 #   bench line (+ CPU baseline), rocprofv3 --kernel-trace --stats summary of the same command, PMC passes.
-# Everything lands under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+# Everything lands under gpurun_out/<tag>/ ; copy what should be judged into profiles/ (tools/collect_profiles.sh), then re-run the five
+# bench lines with the restamped profiles/pmc_latest.json in place (tools/rebench_stamped.sh): the lines of THIS script carry no PMC fields.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1

@@ -1,0 +1,8 @@
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r03_j_rebench; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+run() { local name=$1; shift; python $R/bench.py --steps 300 "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
+run cfg1
+run standing_h10 --workload standing --horizon 10
+run standing_h14 --workload standing --horizon 14
+run standing_h16 --workload standing --horizon 16
+run trot_h16 --config 3
+ls -la $OUT
