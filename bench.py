@@ -13,6 +13,11 @@ the timing barrier / MAX and, with --gather, ONE all_gather_into_tensor of the
 48-byte result rows per step (consumers that need every force on
 every GPU).
 
+Timing: the K-step region of the contract (barrier + torch.cuda.synchronize on both sides, MAX over ranks) is run
+`repeats` times (default 25, fewer when a region takes long); value / ms_per_step are the MEDIAN region's,
+ms_per_step_min / _max the spread.  N > 1: `rank_devices` lists every rank's device name, PCI bus id and uuid,
+`rccl_world_size` the size of the RCCL communicator that carried the barriers.
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      bound "fp64_valu": the kernel issues vector fp64 (no MFMA; on MI355X the dense
                 fp64 MFMA peak equals the fp64 vector peak, 78.6 TFLOP/s).  `achieved` = the
@@ -160,6 +165,10 @@ def main():
                          "reference's Standing gait, ConvexMPCLocomotion.cpp:35: n_r = 12 h); 'trot' = trot at --horizon")
     ap.add_argument("--horizon", type=int, default=10, help="for --workload standing / trot (reference: 10, 14, 16)")
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (override)")
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="the K-step timed region (barrier + synchronize on both sides, MAX over ranks) is run R times; the "
+                         "contract fields come from the MEDIAN repeat (min / max reported beside it).  R is cut down when "
+                         "R x K steps would take more than ~10 s (never below 3)")
     ap.add_argument("--settle", type=float, default=0.3,
                     help="seconds of untimed load before the W warmup steps (GPU clock ramp); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -224,12 +233,12 @@ def main():
     h = b["horizon"]
 
     mpc = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=max(16, h))
-    mpc.setup(b["dt"], h, b["mu"], b["f_max"])
     max_stance = int((b["gait"] != 0).sum(1).max())
     min_stance = int((b["gait"] != 0).sum(1).min())
-    if not args.no_hint:
+    if not args.no_hint:                   # (before setup: qmpc_setup allocates the pools of the classes it can reach)
         mpc.set_max_stance(max_stance)     # the caller built the contact tables, it knows their bounds
         mpc.set_min_stance(min_stance)
+    mpc.setup(b["dt"], h, b["mu"], b["f_max"])
     d = mpc.upload(b)
     o = mpc.alloc_outputs(per_gpu, full=False, iters=True)
     inp, out = mpc.make_args(d, o)
@@ -284,24 +293,50 @@ def main():
     for _ in range(args.warmup):
         one_step()
     sync_all()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        one_step()
-    ev1.record(stream)
-    sync_all()
-    elapsed_local = time.perf_counter() - t0
-    elapsed = elapsed_local
-    ev_ms = ev0.elapsed_time(ev1)           # HIP events on the launch stream
+    # ---- the timed region: EXACTLY K steps between barrier + synchronize, R times over; every repeat is a complete
+    # measurement by the contract's rules (MAX over ranks), the line reports the median one.  (One 20-step region at batch
+    # 1024 is 0.9 ms: a single sample of it moves by several per cent from run to run.)
+    def timed_region():
+        sync_all()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(args.steps):
+            one_step()
+        e1.record(stream)
+        sync_all()
+        return time.perf_counter() - t0, e0, e1
+
+    first_el, e0, e1 = timed_region()
+    regions = [(first_el, e0.elapsed_time(e1))]
+    R = max(args.repeats, 1)
+    if R > 3 and first_el * R > 10.0:
+        R = max(3, int(10.0 / first_el))
+    if dist is not None:   # every rank must run the same number of regions
+        rt = torch.tensor([R], dtype=torch.int32, device=f"cuda:{dev}")
+        dist.broadcast(rt, 0)
+        R = int(rt.item())
+    for _ in range(R - 1):
+        el, e0, e1 = timed_region()
+        regions.append((el, e0.elapsed_time(e1)))   # HIP events on the launch stream
+    local_el = [r[0] for r in regions]
     per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed_local], dtype=torch.float64, device=f"cuda:{dev}")
+        t = torch.tensor(local_el, dtype=torch.float64, device=f"cuda:{dev}")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        per_rank = [float(x.item()) for x in allt]
-        elapsed = max(per_rank)
+        mat = torch.stack(allt).cpu().numpy()          # [rank][repeat]
+        region_el = mat.max(0)                          # MAX over ranks, per repeat
+    else:
+        mat = None
+        region_el = np.array(local_el)
+    order = np.argsort(region_el)
+    med = int(order[len(order) // 2])                   # the median repeat (an actual measurement, not an average)
+    elapsed = float(region_el[med])
+    ev_ms = regions[med][1]
+    if mat is not None:
+        per_rank = [float(x) for x in mat[:, med]]
 
     # ---- extra (not part of the contract fields): the same K steps with two independent
     # batches in flight on two HIP streams.  At batch 1024 a launch is exactly one round of
@@ -313,10 +348,10 @@ def main():
         streams = [torch.cuda.Stream(dev) for _ in range(2)]
         ctx = [(mpc, inp, out)]
         mpc2 = BatchedConvexMPC(dev, max_batch=per_gpu, max_horizon=max(16, h))
-        mpc2.setup(b["dt"], h, b["mu"], b["f_max"])
         if not args.no_hint:
             mpc2.set_max_stance(max_stance)
             mpc2.set_min_stance(min_stance)
+        mpc2.setup(b["dt"], h, b["mu"], b["f_max"])
         o2 = mpc2.alloc_outputs(per_gpu, full=False, iters=True)
         inp2, out2 = mpc2.make_args(d, o2)            # same resident inputs, its own outputs
         ctx.append((mpc2, inp2, out2))
@@ -371,6 +406,19 @@ def main():
                       "note": "K steps, each followed by one all-gather of every rank's grf[shard][12] rows (max over ranks); "
                               "the contract fields are the collective-free run unless --gather was given"}
 
+    # who took part: one line per rank (device name, PCI bus id, uuid), so that a scaling record proves N distinct GPUs
+    rank_devices = None
+    if dist is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev, "device_name": pr.name,
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff,
+                                                  getattr(pr, "pci_device_id", 0) & 0xff),
+                "uuid": str(getattr(pr, "uuid", "")), "gcn_arch": getattr(pr, "gcnArchName", ""),
+                "host": os.uname().nodename}
+        allo = [None] * world
+        dist.all_gather_object(allo, mine)
+        rank_devices = allo
+
     status = o["status"].cpu().numpy()
     iters = o["iters"].cpu().numpy()
     grf_host = o["grf"].cpu().numpy()
@@ -401,7 +449,11 @@ def main():
                     if ent.get("kernel_source_sha") == kernel_source_hash():
                         traffic = ent.get("hbm_bytes_per_launch")       # (per step: summed over the step's kernels)
                         executed = ent.get("fp64_flops_per_launch")
-                        pmc_extra = {"lds_bank_conflict_rate": ent.get("lds_bank_conflict_rate"),
+                        pmc_extra = {"pmc_measured_in_this_run": False,
+                                     "pmc_fields": "traffic, executed_*, lds_bank_conflict_rate, wave_cycle_shares, rocprof: copied from "
+                                                   "the committed rocprofv3 collection named in pmc_profile (same kernel source hash); "
+                                                   "kernel_ms_hip_events, achieved, frac: measured in this run",
+                                     "lds_bank_conflict_rate": ent.get("lds_bank_conflict_rate"),
                                      "wave_cycle_shares": ent.get("wave_cycle_shares"),
                                      "rocprof": ent.get("rocprof"), "pmc_profile": ent.get("profile")}
                         pmc_note = f"PMC counters from {ent.get('profile')} (same kernel source)"
@@ -427,6 +479,12 @@ def main():
             "value": value, "unit": "QP solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": int(len(region_el)),
+            "ms_per_step_min": float(region_el.min()) / args.steps * 1e3,
+            "ms_per_step_median": elapsed / args.steps * 1e3,
+            "ms_per_step_max": float(region_el.max()) / args.steps * 1e3,
+            "timing": "value / ms_per_step = the MEDIAN of `repeats` timed regions of exactly `steps` steps each (barrier + "
+                      "synchronize on both sides, MAX over ranks per region)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"caller-side pipeline ({args.caller_side}: command -> record -> solve -> body-frame forces), " if args.caller_side else "") +
@@ -464,6 +522,12 @@ def main():
                              "alg_bytes_per_qp": alg_bytes_per_qp(h),
                              "note": "728 B in + 48 B out per robot at h=10: tiny by construction"},
         }
+        if rank_devices is not None:
+            res["rccl_world_size"] = world if os.environ.get("QMPC_BENCH_BACKEND", "nccl") == "nccl" else None
+            res["world_size"] = world
+            res["backend"] = os.environ.get("QMPC_BENCH_BACKEND", "nccl")
+            res["rank_devices"] = rank_devices
+            res["distinct_devices"] = len({(r.get("pci_bus_id"), r.get("uuid")) for r in rank_devices})
         if per_rank is not None:
             res["per_rank"] = {"elapsed_s": per_rank,
                                "qp_per_s": [per_gpu * args.steps / t for t in per_rank],

@@ -167,7 +167,12 @@ int qmpc_set_model(qmpc_handle h, int model);
  * ConvexMPCLocomotion.cpp:644-648).  With use_jcqp != 0 qmpc_solve / qmpc_solve_host reproduce THAT
  * iteration on the GPU (same updates, same stopping rule; iters = ADMM iterations, QMPC_ST_MAXITER when
  * the residual test never passed); use_jcqp = 0 (default) is the exact active-set solve, which is what
- * the reference's qpOASES path returns.  qmpc_solve_commands always solves exactly. */
+ * the reference's qpOASES path returns.  qmpc_solve_commands always solves exactly.
+ * Limits at horizons above QMPC_LONG_HORIZON: use_jcqp = 1 keeps 12 h > 192 variables, for which there is no ADMM
+ * instantiation -- qmpc_settings_jcqp (handle already set up for such a horizon) and qmpc_setup (mode 1 already
+ * selected) return QMPC_ERR_ARG and leave the handle unchanged, no solve call ever fails half-way for it; with
+ * use_jcqp = 2 a robot whose reduced size exceeds 192 variables is REPORTED (QMPC_ST_WS_FULL, zero forces), not
+ * solved by the exact engine under the ADMM's name. */
 int qmpc_settings_jcqp(qmpc_handle h, int use_jcqp, int max_iter, double rho, double sigma,
                        double solver_alpha, double terminate);
 
@@ -187,8 +192,8 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 
 /* Decoupled path of the 128- and 192-row size classes (n_r > 96: all four feet down, dense random contact tables).
  * on (default): the robot's condensed Hessian is inverted by a sweep kernel that leaves the inverse in a work item
- * in global memory (128 / 288 KiB per robot of the largest batch, of which the lower block triangle is written;
- * allocated when a call first reaches the class or by qmpc_reserve), and the active set is run by a second kernel,
+ * in global memory (128 / 288 KiB per item, of which the lower block triangle is written; a bounded pool allocated by
+ * qmpc_setup, see qmpc_set_chunks), and the active set is run by a second kernel,
  * one robot per small workgroup -- the robots with the most rows violated at the unconstrained minimiser first --
  * with the rank-1 events of the method in the register file of helper waves, instead of one workgroup pinning a whole
  * CU for the whole solve.  Same unique minimiser.  A robot whose history outgrows the engine's registers and LDS
@@ -209,13 +214,17 @@ int qmpc_set_split(qmpc_handle h, int mode);
  * measured on MI355X not faster than the iteration it replaces: ~3.1 k cycles per forced change against
  * ~4.9 k per iteration, and 20 % more changes.  `iters` counts every forced change like an iteration. */
 int qmpc_set_block_start(qmpc_handle h, int on);
-/* Chunks of the decoupled path: the robots of such a class are processed as n consecutive chunks whose sweep and engine
- * kernels are enqueued on the handle's own auxiliary streams (a chunk's active set runs beside the next chunk's sweep)
- * and joined into the caller's stream before the call returns control of it.  0 (default) = chosen by batch size
- * (1 below 192 robots ... 8 from 2048), 1 = everything on the caller's stream, at most 8.  Results do not depend on it. */
+/* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for
+ * the 128-row class / 192-row class / large problems -- whatever max_batch is; a call with more robots than items runs the
+ * class as consecutive chunks (producer kernel, engine kernel, producer kernel, ...) on the caller's stream, the pool reused
+ * from chunk to chunk.  Results do not depend on the chunking (tested).  qmpc_set_chunks (test hook): at least n chunks
+ * (0 / 1 = as few as the pool allows; at most 64). */
 int qmpc_set_chunks(qmpc_handle h, int n);
-/* Allocate now whatever the current setup and stance hints can need later (the decoupled path's work items), so
- * that no solve call allocates -- call it before capturing solves into a graph. */
+/* Every device allocation of a handle happens in qmpc_create, qmpc_setup (what the horizon makes reachable), the stance
+ * hints, qmpc_set_split and here -- NEVER inside a solve call: qmpc_solve / qmpc_solve_commands only enqueue kernels on the
+ * caller's stream (no memset nodes either: they replay wrongly with ROCm 7.2), so they can be captured into a hipGraph and replayed
+ * (tests/test_gpu_parity.py::test_solve_is_graph_capturable).  qmpc_reserve repeats the allocation step for the current
+ * setup; it is implied by qmpc_setup and kept for callers of earlier versions. */
 int qmpc_reserve(qmpc_handle h);
 
 /* Warm start across MPC cycles (the reference cold-starts every solve,
@@ -287,6 +296,8 @@ int qmpc_set_debug_pool_busy(qmpc_handle h, int on);
  * to the host after a solve: the inverse (ld x ld doubles, ld = 128 / 192 / 448; the 128- / 192-row classes write the lower block
  * triangle only), x_u (ld doubles), {rid, n, nst, status bits} (4 ints).  Any pointer may be NULL. */
 int qmpc_debug_read_item(qmpc_handle h, int which, int item, double* hinv_host, double* xu_host, int* hdr4);
+/* Test hook: the handle's three counter sets (3 x 256 ints: two ping-ponged by eager calls, one for captured calls) -> host. */
+int qmpc_debug_read_counts(qmpc_handle h, int* host768);
 /* Profiling hook: DEVICE buffer clk[B][16] receiving shader-clock stamps at
  * the kernel's phase boundaries (NULL = off). */
 int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);

@@ -90,6 +90,17 @@ extern "C" hipError_t qmpc_launch_swing(const float* p0, const float* pf, const 
                                         const float* swing_time, float* p, float* v, float* a, int n_feet,
                                         hipStream_t stream);
 
+// Small device arrays are (re)set by this kernel, never by hipMemsetAsync: a memset node captured into a hipGraph writes
+// garbage on replay with this runtime (ROCm 7.2: the counters came back as {512, 24111, 1, 24106, ...}; measured with
+// tools/dbg/graph_probe.py), a kernel node replays correctly
+__global__ void qmpc_fill_ints_kernel(int* p, int n, int v) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) p[k] = v;
+}
+static hipError_t fill_ints(int* p, int n, int v, hipStream_t stream) {
+  hipLaunchKernelGGL(qmpc_fill_ints_kernel, dim3((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), dim3(256), 0, stream, p, n, v);
+  return hipGetLastError();
+}
+
 struct qmpc_ctx {
   int device = 0;
   int max_batch = 0, max_horizon = 0;
@@ -104,7 +115,7 @@ struct qmpc_ctx {
   float leg_geom[4] = {0.062f, 0.209f, 0.195f, 0.004f};  // MiniCheetah.h:31-37 (abad, hip, knee, knee Y offset)
   double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
   int* d_lists = nullptr;      // [4][max_batch] robot ids handed to classes 4, 2 and 3, and to the large-problem producer
-  int* d_counts = nullptr;     // [2 sets][QMPC_COUNTERS] (layout in qmpc_device.h); ping-ponged between calls
+  int* d_counts = nullptr;     // [3 sets][QMPC_COUNTERS] (layout in qmpc_device.h); sets 0 / 1 ping-ponged between calls, set 2: calls captured into a graph
   // decoupled path (sweep kernel -> work items -> engine kernel) of the 128- and 192-row classes: [0] class 2, [1] class 3
   int split = 1;               // qmpc_set_split: 0 off, 1 automatic (by batch size), 2 always; QMPC_NO_SPLIT=1 in the environment: 0 at creation
   double* d_wk_hinv[3] = {nullptr, nullptr, nullptr};
@@ -112,14 +123,10 @@ struct qmpc_ctx {
   QmpcWorkHdr* d_wk_hdr[3] = {nullptr, nullptr, nullptr};  // [2]: the large problems (192 < n_r <= 432)
   int* d_wk_order[3] = {nullptr, nullptr, nullptr};
   double* d_wk_ovf[3] = {nullptr, nullptr, nullptr};  // engine kernels' overflow event pools (one slice per resident workgroup)  // [QMPC_ORDER_BUCKETS][max_batch] item indices, hardest robots first
-  int wk_cap[3] = {0, 0, 0};
-  int* d_fb_lists = nullptr;   // [2][max_batch] robots the engine kernels hand back
-  // chunked launches of the decoupled path: sweep kernels of consecutive chunks on aux[0], engine kernels alternating
-  // on aux[1] / aux[2], so that a chunk's active set runs beside the next chunk's sweep; joined into the caller's stream
-  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_chunk[QMPC_MAX_CHUNKS] = {}, ev_join[3] = {nullptr, nullptr, nullptr};
+  int wk_cap[3] = {0, 0, 0};    // work items per class: a bounded pool, min(max_batch, QMPC_ITEMS_*) -- ensure_pools
+  int* d_fb_lists = nullptr;   // [3][max_batch] robots the engine kernels hand back (128-row, 192-row, large problems)
   bool block = false;          // qmpc_set_block_start (experimental, off: measured no faster); QMPC_BLOCK=1 in the environment switches it on at creation
-  int chunks = 0;              // qmpc_set_chunks: 0 = automatic (by batch size), 1 = no chunking
+  int chunks = 0;              // qmpc_set_chunks (test hook): run the item classes in at least this many chunks (0 / 1: as few as the pools allow)
   int dbg_engine_events = 0;   // test hook: events the engine may hold per robot (0 = the compiled capacity)
   unsigned call_no = 0;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
@@ -181,7 +188,17 @@ int fail(qmpc_ctx* c, hipError_t e, const char* what) {
 
 // One stream at a time orders the handle's device state.  A call on a different stream than the
 // previous one waits (on the device, no host block) for everything the previous stream was given.
+// (a stream that is being captured into a graph: the work becomes graph nodes; the legacy null stream cannot capture)
+bool is_capturing(hipStream_t stream) {
+  if (!stream) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
+
 int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
+  // (captured calls: ordering against earlier work of the handle on OTHER streams is the caller's business -- an event
+  //  recorded outside the capture cannot be waited for inside it)
+  if (is_capturing(stream)) return QMPC_OK;
   if (c->has_last && c->last_stream != stream) {
     if (!c->order_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->order_ev, c->last_stream));
@@ -195,12 +212,12 @@ int order_after_previous(qmpc_ctx* c, hipStream_t stream) {
 }  // namespace
 
 namespace {
-int ensure_split(qmpc_ctx* c, int rb);
+int ensure_pools(qmpc_ctx* c);
 }
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 14; }
+int qmpc_abi_version(void) { return 15; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -219,9 +236,9 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   const size_t H = (size_t)max_horizon;
   hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
   if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 4 * (size_t)max_batch);  // ([3]: the large problems, horizons > 16)
-  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 2 * QMPC_COUNTERS);
-  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 2 * QMPC_COUNTERS);
-  if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 2 * (size_t)max_batch);
+  if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 3 * QMPC_COUNTERS);
+  if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 3 * QMPC_COUNTERS);
+  if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 3 * (size_t)max_batch);
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = (ns && ns[0] == '1') ? 0 : 1;
@@ -256,13 +273,6 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_evflags) hipFree(h->d_evflags);
     if (h->d_fb_lists) hipFree(h->d_fb_lists);
     for (int k = 0; k < 3; ++k) {
-      if (h->aux[k]) hipStreamDestroy(h->aux[k]);
-      if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
-    }
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < QMPC_MAX_CHUNKS; ++k)
-      if (h->ev_chunk[k]) hipEventDestroy(h->ev_chunk[k]);
-    for (int k = 0; k < 3; ++k) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
       if (h->d_wk_hdr[k]) hipFree(h->d_wk_hdr[k]);
@@ -281,6 +291,12 @@ int qmpc_destroy(qmpc_handle h) {
 int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   if (!c) return QMPC_ERR_ARG;
   if (horizon <= 0 || horizon > c->max_horizon || !(mu > 0) || !(dt > 0)) return QMPC_ERR_ARG;
+  // use_jcqp = 1 keeps all 12 h variables (SolverMPC.cpp:400-414): beyond 192 rows at horizons above 16, where no ADMM
+  // instantiation exists -- refused HERE (and in qmpc_settings_jcqp), never in the middle of a solve
+  if (c->admm_mode == 1 && horizon > QMPC_LONG_HORIZON) {
+    c->err = "use_jcqp = 1 is limited to horizons <= 16 (12 h variables beyond the 192-row class)";
+    return QMPC_ERR_ARG;
+  }
   // struct problem_setup stores floats (convexMPC_interface.h:13-19)
   c->dt = (double)(float)dt;
   c->mu = (double)(float)mu;
@@ -302,7 +318,7 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   }
   // the tables depend on (dt, horizon) only: the reference's caller repeats setup_problem with the
   // same values before every solve (ConvexMPCLocomotion.cpp:630), which costs nothing here
-  if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h && c->tab_model == c->model) return QMPC_OK;
+  if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h && c->tab_model == c->model) return ensure_pools(c);
   // coefficient tables (see qmpc_device.h); A_ct^3 = 0 makes
   // Adt^d Bdt = dt B + c_d A B + e_d A^2 B exact.
   std::vector<double> t(3 * h + 9 * h * h);
@@ -337,7 +353,9 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   c->tab_h = h;
   c->tab_model = c->model;
   c->is_setup = true;
-  return QMPC_OK;
+  // every pool a solve at this horizon can need is allocated now: no solve call allocates (a hipMalloc synchronises
+  // the device and cannot be captured into a graph)
+  return ensure_pools(c);
 }
 
 int qmpc_set_robot(qmpc_handle c, double mass, const double ibody_diag[3], double gravity) {
@@ -360,13 +378,13 @@ int qmpc_settings(qmpc_handle c, int max_iter, double tol) {
 int qmpc_set_max_stance(qmpc_handle c, int max_stance_footsteps) {
   if (!c || max_stance_footsteps < 0) return QMPC_ERR_ARG;
   c->max_stance = max_stance_footsteps;
-  return QMPC_OK;
+  return ensure_pools(c);  // (a wider hint can make a larger class reachable)
 }
 
 int qmpc_set_min_stance(qmpc_handle c, int min_stance_footsteps) {
   if (!c || min_stance_footsteps < 0) return QMPC_ERR_ARG;
   c->min_stance = min_stance_footsteps;
-  return QMPC_OK;
+  return ensure_pools(c);
 }
 
 int qmpc_set_model(qmpc_handle c, int model) {
@@ -383,6 +401,10 @@ int qmpc_settings_jcqp(qmpc_handle c, int use_jcqp, int max_iter, double rho, do
   if (!c || use_jcqp < 0 || use_jcqp > 2) return QMPC_ERR_ARG;
   if (use_jcqp && (max_iter <= 0 || !(rho > 0) || !(sigma >= 0) || !(solver_alpha > 0) || !(terminate >= 0)))
     return QMPC_ERR_ARG;
+  if (use_jcqp == 1 && c->is_setup && c->horizon > QMPC_LONG_HORIZON) {  // (see qmpc_setup)
+    c->err = "use_jcqp = 1 is limited to horizons <= 16 (12 h variables beyond the 192-row class)";
+    return QMPC_ERR_ARG;
+  }
   c->admm_mode = use_jcqp;
   if (use_jcqp) {
     c->admm_max_iter = max_iter;
@@ -420,7 +442,7 @@ int qmpc_set_split(qmpc_handle c, int on) {
   if (!c) return QMPC_ERR_ARG;
   if (on < 0 || on > 2) return QMPC_ERR_ARG;
   c->split = on;
-  return QMPC_OK;
+  return ensure_pools(c);
 }
 
 int qmpc_set_block_start(qmpc_handle c, int on) {
@@ -430,7 +452,7 @@ int qmpc_set_block_start(qmpc_handle c, int on) {
 }
 
 int qmpc_set_chunks(qmpc_handle c, int n) {
-  if (!c || n < 0 || n > QMPC_MAX_CHUNKS) return QMPC_ERR_ARG;
+  if (!c || n < 0 || n > 64) return QMPC_ERR_ARG;
   c->chunks = n;
   return QMPC_OK;
 }
@@ -444,18 +466,8 @@ int qmpc_set_debug_engine_events(qmpc_handle c, int n) {
 int qmpc_reserve(qmpc_handle c) {
   if (!c) return QMPC_ERR_ARG;
   if (!c->is_setup) return QMPC_ERR_STATE;
-  if (!c->split) return QMPC_OK;
   DeviceGuard g(c->device);
-  // the classes the current horizon and stance hints can reach (same rule as the solve)
-  const int nmax = c->max_stance > 0 ? 3 * c->max_stance : 12 * c->horizon;
-  const int nreach = nmax < 12 * c->horizon ? nmax : 12 * c->horizon;
-  if (nreach > 96 && 3 * c->min_stance <= 128) {
-    if (const int rc = ensure_split(c, 2)) return rc;
-  }
-  if (nreach > 128) {
-    if (const int rc = ensure_split(c, 3)) return rc;
-  }
-  return QMPC_OK;
+  return ensure_pools(c);  // (qmpc_setup and the hint setters have done this already: kept for callers of earlier versions)
 }
 
 int qmpc_set_debug_pool_busy(qmpc_handle c, int on) {
@@ -485,6 +497,14 @@ int qmpc_debug_read_item(qmpc_handle c, int which, int item, double* hinv_host, 
   return QMPC_OK;
 }
 
+int qmpc_debug_read_counts(qmpc_handle c, int* host768) {
+  if (!c || !host768) return QMPC_ERR_ARG;
+  DeviceGuard g(c->device);
+  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipMemcpy(host768, c->d_counts, sizeof(int) * 3 * QMPC_COUNTERS, hipMemcpyDeviceToHost));
+  return QMPC_OK;
+}
+
 int qmpc_set_debug_clock(qmpc_handle c, long long* clk_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_clk = clk_dev;
@@ -502,35 +522,96 @@ bool command_ok(const qmpc_command* cmd) {
          !(cmd->gait_type && !cmd->stand_traj);  // a standing robot needs its stand_traj row
 }
 
-// work items of the decoupled path for size class rb (2 or 3): one per robot of the largest batch (the inverse is
-// 128 / 288 KiB per robot).  Allocated on the first call that can reach the class (qmpc_reserve does it up front)
-int ensure_split(qmpc_ctx* c, int rb) {  // (rb 5: the large problems, 448-row items)
-  const int k = rb == 2 ? 0 : (rb == 3 ? 1 : 2);
-  if (c->d_wk_hinv[k]) return QMPC_OK;
-  const size_t ld = rb == 2 ? 128 : (rb == 3 ? 192 : QMPC_BIG_LD), cap = (size_t)c->max_batch;
-  HIP_TRY(c, hipMalloc(&c->d_wk_hinv[k], sizeof(double) * cap * ld * ld));
-  HIP_TRY(c, hipMalloc(&c->d_wk_xu[k], sizeof(double) * cap * ld));
-  HIP_TRY(c, hipMalloc(&c->d_wk_hdr[k], sizeof(QmpcWorkHdr) * cap));
-  HIP_TRY(c, hipMalloc(&c->d_wk_order[k], sizeof(int) * QMPC_ORDER_BUCKETS * cap));
+// Which size classes a solve launches, and which of them through work items (the decoupled path): ONE rule, used by
+// the solve and by the allocation of the pools.
+//   chain 1 -> 4 -> 2 -> 3 (64 / 96 / 128 / 192 padded rows), n_r = 3 * stance foot-steps; classes k0 .. k1 - 1 are
+//   launched; long_h: the large-problem stage behind the 192-row class (192 < n_r <= 432, horizons above 16)
+struct ClassPlan {
+  int k0 = 0, k1 = 0;
+  bool long_h = false;
+  bool split[4] = {false, false, false, false};
+};
+const int kChain[4] = {1, 4, 2, 3};
+const int kRows[4] = {64, 96, 128, 192};
+
+ClassPlan plan_classes(const qmpc_ctx* c, int admm_mode, bool warm) {
+  ClassPlan pl;
+  const bool full_problem = (admm_mode == 1), exact_cold = !admm_mode && !warm;
+  const int h = c->horizon;
+  const int nmax = 12 * h;
+  int nclass = 4;
+  for (int k = 0; k < 4; ++k)
+    if (nmax <= kRows[k]) { nclass = k + 1; break; }
+  // a caller that knows its gaits can bound the reduced size (qmpc_set_max_stance):
+  // larger classes are then not even launched; violators are flagged WS_FULL
+  pl.k1 = nclass;
+  if (c->max_stance > 0 && !full_problem) {  // (use_jcqp = 1: every foot-step is a variable block, n_r = 12 h for all robots)
+    const int nb = 3 * c->max_stance;
+    int hc = 4;
+    for (int k = 0; k < 4; ++k)
+      if (nb <= kRows[k]) { hc = k + 1; break; }
+    if (hc < pl.k1) pl.k1 = hc;
+  }
+  // ... and with a lower bound the classes that are too small for every robot are skipped
+  while (pl.k0 + 1 < pl.k1 && 3 * (full_problem ? 4 * h : c->min_stance) > kRows[pl.k0]) ++pl.k0;
+  if (h > QMPC_LONG_HORIZON) {
+    // long horizons (up to K_MAX_GAIT_SEGMENTS = 36): the 192-row class alone has the threads (12 h tracking-error
+    // entries, one per thread) and the LDS (h x h coefficient tables) to assemble them -- it takes every robot; one with
+    // more than 64 stance foot-steps goes on to the large-problem path
+    pl.k0 = 3;
+    pl.k1 = 4;
+    // (the large-problem stage: skipped when the caller's size hint, qmpc_set_max_stance, rules such robots out -- a
+    //  violator is reported like any other -- and for the JCQP alternate, which has no large-problem instantiation:
+    //  its robots beyond 192 rows are REPORTED, QMPC_ST_WS_FULL, not solved by another method)
+    pl.long_h = !(c->max_stance > 0 && 3 * c->max_stance <= 192) && !admm_mode;
+  }
+  // decoupled path (128- and 192-row classes, exact solve, cold start): sweep kernel -> work items -> engine kernel ->
+  // (rarely) the monolithic kernel on the robots the engine handed back.  Automatic: a small batch is latency-bound --
+  // one workgroup per CU either way -- and the one-kernel path has one launch and no trip through L2 on it: measured
+  // break-even ~300 robots in the 128-row class, below 128 in the 192-row class.  Decided by the HANDLE's size, not
+  // the call's: a robot's result does not depend on the batch it is solved in -- the two paths agree to ~1e-14
+  // relative, not bit for bit
+  for (int k = pl.k0; k < pl.k1; ++k) {
+    const bool big = c->split == 2 || c->max_batch >= (kChain[k] == 2 ? 384 : 128);
+    pl.split[k] = c->split && big && (kChain[k] == 2 || kChain[k] == 3) && exact_cold;
+  }
+  return pl;
+}
+
+// one pool of work items: sk 0 = 128-row class, 1 = 192-row class, 2 = large problems (448-row items)
+int ensure_items(qmpc_ctx* c, int sk) {
+  if (c->d_wk_hinv[sk]) return QMPC_OK;
+  static const int lim[3] = {QMPC_ITEMS_C2, QMPC_ITEMS_C3, QMPC_ITEMS_BIG};
+  const int rb = sk == 0 ? 2 : (sk == 1 ? 3 : 5);
+  const size_t ld = sk == 0 ? 128 : (sk == 1 ? 192 : QMPC_BIG_LD);
+  const size_t cap = (size_t)(c->max_batch < lim[sk] ? c->max_batch : lim[sk]);
+  HIP_TRY(c, hipMalloc(&c->d_wk_hinv[sk], sizeof(double) * cap * ld * ld));
+  HIP_TRY(c, hipMalloc(&c->d_wk_xu[sk], sizeof(double) * cap * ld));
+  HIP_TRY(c, hipMalloc(&c->d_wk_hdr[sk], sizeof(QmpcWorkHdr) * cap));
+  HIP_TRY(c, hipMalloc(&c->d_wk_order[sk], sizeof(int) * QMPC_ORDER_BUCKETS * cap));
   {
     // (the engine grid never exceeds the resident workgroups: slice = blockIdx.x)
     size_t wgs = (size_t)qmpc_engine_resident(rb);
     if (wgs == 0 || wgs > cap) wgs = cap;
-    const size_t ev = rb == 2 ? 128 + 64 : (rb == 3 ? 192 + 128 : QMPC_BIG_LD + 192);
-    HIP_TRY(c, hipMalloc(&c->d_wk_ovf[k], sizeof(double) * wgs * QMPC_ENGINE_OVF_EVENTS * ev));
+    const size_t ev = sk == 0 ? 128 + 64 : (sk == 1 ? 192 + 128 : QMPC_BIG_LD + 192);
+    HIP_TRY(c, hipMalloc(&c->d_wk_ovf[sk], sizeof(double) * wgs * QMPC_ENGINE_OVF_EVENTS * ev));
   }
-  c->wk_cap[k] = (int)cap;
+  c->wk_cap[sk] = (int)cap;
   return QMPC_OK;
 }
 
-int ensure_aux(qmpc_ctx* c) {
-  if (c->aux[0]) return QMPC_OK;
-  for (int k = 0; k < 3; ++k) {
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
-  }
-  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  for (int k = 0; k < QMPC_MAX_CHUNKS; ++k) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
+// Every pool the current setup, stance hints and split mode can reach, allocated NOW (qmpc_setup, the hint setters,
+// qmpc_set_split, qmpc_reserve call this): a solve call never allocates.  The pools are bounded by QMPC_ITEMS_*,
+// not by max_batch: a call with more robots than items runs the class in consecutive chunks.
+int ensure_pools(qmpc_ctx* c) {
+  if (!c->is_setup) return QMPC_OK;
+  DeviceGuard g(c->device);
+  const ClassPlan pl = plan_classes(c, 0, false);
+  for (int k = pl.k0; k < pl.k1; ++k)
+    if (pl.split[k])
+      if (const int rc = ensure_items(c, kChain[k] == 2 ? 0 : 1)) return rc;
+  if (pl.long_h)
+    if (const int rc = ensure_items(c, 2)) return rc;
   return QMPC_OK;
 }
 
@@ -555,6 +636,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   hipStream_t stream = (hipStream_t)stream_;
   DeviceGuard g(c->device);
   const int h = c->horizon;
+  const bool capturing = is_capturing(stream);
   if (const int rc = order_after_previous(c, stream)) return rc;
 
   QmpcParams P;
@@ -609,209 +691,159 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_aux = c->dbg_aux;
   P.dbg_clk = c->dbg_clk;
 
-  // size classes by padded rows: 64 (kernel class 1), 96 (class 4), 128 (class 2), 192 (class 3);
-  // n_r = 3 * stance foot-steps.  The first class is launched over the whole batch; a robot that
-  // does not fit appends itself to the list of the next one.
-  static const int chain[4] = {1, 4, 2, 3};
-  static const int rows[4] = {64, 96, 128, 192};
-  const int nmax = 12 * h;
-  int nclass = 4;
-  for (int k = 0; k < 4; ++k)
-    if (nmax <= rows[k]) { nclass = k + 1; break; }
-  // a caller that knows its gaits can bound the reduced size (qmpc_set_max_stance):
-  // larger classes are then not even launched; violators are flagged WS_FULL
-  int nclass_eff = nclass;
-  const bool full_problem = (P.admm_mode == 1);  // every foot-step is a variable block: n_r = 12 h for all robots
-  if (c->max_stance > 0 && !full_problem) {
-    const int nb = 3 * c->max_stance;
-    int hc = 4;
-    for (int k = 0; k < 4; ++k)
-      if (nb <= rows[k]) { hc = k + 1; break; }
-    if (hc < nclass_eff) nclass_eff = hc;
-  }
   P.ovpool = c->d_ovpool;
   P.ov_nslice = c->ov_nslice;
   P.evpool = c->d_evpool;
   P.evflags = c->d_evflags;
   P.ev_nslot = c->ev_nslot;
   P.ev_spin = c->dbg_pool_busy ? 4 : (1 << 16);
-  const unsigned set = c->call_no & 1u;
-  c->call_no++;
-  int* cnt = c->d_counts + QMPC_COUNTERS * set;             // this call's counters (one per list)
-  int* cnt_next = c->d_counts + QMPC_COUNTERS * (set ^ 1u); // cleared by this call's first kernel
-  P.ov_count = cnt + 7;                         // slices of the overflow pool handed out in this call
-  // ... and with a lower bound the classes that are too small for every robot are skipped
-  int k0 = 0;
-  while (k0 + 1 < nclass_eff && 3 * (full_problem ? 4 * h : c->min_stance) > rows[k0]) ++k0;
-  if (h > QMPC_LONG_HORIZON) {
-    // long horizons (up to K_MAX_GAIT_SEGMENTS = 36): the 192-row class alone has the threads (12 h tracking-error
-    // entries, one per thread) and the LDS (h x h coefficient tables) to assemble them -- it takes every robot; one with
-    // more than 64 stance foot-steps goes on to the large-problem path below
-    if (full_problem) return QMPC_ERR_ARG;  // (use_jcqp = 1 keeps all 12 h variables: beyond 192 rows)
-    k0 = 3;
-    nclass_eff = 4;
+
+  // ---- the launch plan, and everything that can refuse the call, BEFORE the call counter moves: the counter sets
+  // ping-pong between calls and each call's first kernel zeroes the NEXT call's set, so a call that took a set without
+  // launching would leave the following call on counters nobody cleared
+  const ClassPlan pl = plan_classes(c, P.admm_mode, P.ws != nullptr);
+  if (P.admm_mode == 1 && h > QMPC_LONG_HORIZON) return QMPC_ERR_ARG;  // (refused by qmpc_setup / qmpc_settings_jcqp already)
+  for (int k = pl.k0; k < pl.k1; ++k)
+    if (pl.split[k] && !c->d_wk_hinv[kChain[k] == 2 ? 0 : 1]) {
+      c->err = "work-item pool missing (qmpc_setup / qmpc_reserve allocate it)";
+      return QMPC_ERR_STATE;
+    }
+  if (pl.long_h && !c->d_wk_hinv[2]) {
+    c->err = "large-problem pool missing (qmpc_setup / qmpc_reserve allocate it)";
+    return QMPC_ERR_STATE;
   }
-  // (the large-problem stage behind the 192-row class: three more launches per call, normally empty -- skipped when the
-  //  caller's size hint, qmpc_set_max_stance, rules such robots out; a violator is reported like any other)
-  const bool long_h = h > QMPC_LONG_HORIZON && !(c->max_stance > 0 && 3 * c->max_stance <= 192);
-  for (int k = k0; k < nclass_eff; ++k) {
-    P.list = k > k0 ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
-    P.count = k > k0 ? cnt + (k - 1) : nullptr;
-    P.qhead = k > k0 ? cnt + 4 + (k - 1) : nullptr;
-    P.clear_counts = k > k0 ? nullptr : cnt_next;
-    const bool more = k + 1 < nclass_eff;
+  int* cnt;       // this call's counters
+  int* cnt_next;  // the set this call's first kernel clears (the next call's)
+  if (capturing) {
+    // a call captured into a hipGraph is replayed with the SAME kernel arguments every time: it cannot take part in
+    // the ping-pong (its set would be dirty from the previous replay).  Captured calls use a set of their own, cleared
+    // by a small kernel node in front of the call's kernels; the eager calls' two sets are not touched
+    cnt = c->d_counts + QMPC_COUNTERS * 2;
+    cnt_next = nullptr;
+    HIP_TRY(c, fill_ints(cnt, QMPC_COUNTERS, 0, stream));
+  } else {
+    const unsigned set = c->call_no & 1u;
+    c->call_no++;
+    cnt = c->d_counts + QMPC_COUNTERS * set;
+    cnt_next = c->d_counts + QMPC_COUNTERS * (set ^ 1u);
+  }
+  P.ov_count = cnt + 7;                         // slices of the overflow pool handed out in this call
+  bool first = true;                            // the next launch is the first of the call: it carries clear_counts
+
+  // one item class of the decoupled path (sk 0 / 1: sweep kernel of class rb; sk 2: the large-problem producer): the
+  // robots [0, batch) -- or the entries of `list` -- in consecutive chunks of at most wk_cap[sk], every chunk a
+  // producer launch and an engine launch on the caller's stream, the pool reused from chunk to chunk
+  auto run_items = [&](const QmpcParams& base, int sk, int rb, const int* list, int* count) -> int {
+    QmpcParams A = base;
+    A.wk_hinv = c->d_wk_hinv[sk];
+    A.wk_xu = c->d_wk_xu[sk];
+    A.wk_hdr = c->d_wk_hdr[sk];
+    A.wk_order = c->d_wk_order[sk];
+    A.wk_ovf = c->d_wk_ovf[sk];
+    A.wk_ld = sk == 0 ? 128 : (sk == 1 ? 192 : QMPC_BIG_LD);
+    A.wk_cap = c->wk_cap[sk];
+    A.wk_base = 0;
+    A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
+    A.wk_block = (sk < 2 && c->block) ? 1 : 0;
+    A.fb_list = c->d_fb_lists + (size_t)sk * c->max_batch;
+    A.fb_count = cnt + QMPC_CNT_FB + sk;
+    A.list = list;
+    A.count = count;
+    int nch = (batch + c->wk_cap[sk] - 1) / c->wk_cap[sk];
+    if (c->chunks > nch) nch = c->chunks < batch ? c->chunks : batch;
+    const int per = (batch + nch - 1) / nch;  // (<= wk_cap[sk])
+    for (int ch = 0; ch < nch; ++ch) {
+      const int lo = ch * per, hi = (lo + per < batch) ? lo + per : batch;
+      if (lo >= hi) break;
+      int* grp = cnt + QMPC_CNT_GRP(sk, ch & 1);
+      A.wk_count = grp;
+      A.wk_qhead = grp + 1;
+      A.qhead = list ? grp + 2 : nullptr;
+      A.wk_bucket = grp + 8;
+      A.wk_zero = nullptr;
+      A.rid0 = lo;
+      A.list_hi = hi;
+      A.clear_counts = first ? cnt_next : nullptr;
+      first = false;
+      int grid = hi - lo;
+      if (list || sk == 2) {
+        const int res = sk == 2 ? qmpc_resident_blocks(3) : qmpc_resident_sweep(rb);  // (the large-problem producer has the 192-row class's footprint)
+        if (res > 0 && res < grid) grid = res;
+      }
+      if (sk == 2) HIP_TRY(c, qmpc_big_launch(&A, grid, stream));
+      else HIP_TRY(c, qmpc_launch_sweep(rb, &A, grid, stream));
+      QmpcParams B = A;  // the engine: one robot per workgroup, the chunk's items as a queue
+      B.list = nullptr; B.count = nullptr; B.qhead = nullptr; B.clear_counts = nullptr;
+      B.next_list = nullptr; B.next_count = nullptr;
+      B.wk_zero = (ch + 1 < nch) ? cnt + QMPC_CNT_GRP(sk, (ch + 1) & 1) : nullptr;
+      int gb = hi - lo;
+      {
+        const int res = qmpc_engine_resident(sk == 2 ? 5 : rb);
+        if (res > 0 && res < gb) gb = res;
+      }
+      HIP_TRY(c, qmpc_engine_launch(sk == 2 ? 5 : rb, &B, gb, stream));
+    }
+    // robots handed back (event capacity exceeded, lost definiteness): the monolithic kernel, list-consuming.  The
+    // large problems have no class to fall back to: the 192-row class's stage 0 REPORTS them (QMPC_ST_WS_FULL)
+    QmpcParams F = base;
+    F.list = A.fb_list; F.count = A.fb_count; F.qhead = cnt + QMPC_CNT_FBQ + sk; F.clear_counts = nullptr;
+    F.list_hi = 0x7fffffff;
+    F.rid0 = 0;
+    F.next_list = nullptr; F.next_count = nullptr;
+    F.status_or = sk == 2 ? 0 : QMPC_DEV_ST_FALLBACK;
+    const int frb = sk == 0 ? 2 : 3;
+    if (frb == 3 && c->d_evflags)
+      HIP_TRY(c, fill_ints(c->d_evflags, c->ev_nslot, c->dbg_pool_busy ? 1 : 0, stream));
+    int gf = batch;
+    {
+      const int res = qmpc_resident_blocks(frb);
+      if (res > 0 && res < gf) gf = res;
+    }
+    HIP_TRY(c, qmpc_launch(frb, &F, gf, stream));
+    return QMPC_OK;
+  };
+
+  // size classes by padded rows: 64 (kernel class 1), 96 (class 4), 128 (class 2), 192 (class 3);
+  // n_r = 3 * stance foot-steps.  The first class is launched over the whole batch; a robot that
+  // does not fit appends itself to the list of the next one.
+  for (int k = pl.k0; k < pl.k1; ++k) {
+    const bool listed = k > pl.k0;
+    P.list = listed ? c->d_lists + (size_t)(k - 1) * c->max_batch : nullptr;
+    P.count = listed ? cnt + (k - 1) : nullptr;
+    P.qhead = listed ? cnt + 4 + (k - 1) : nullptr;
+    const bool more = k + 1 < pl.k1;
     P.next_list = more ? c->d_lists + (size_t)k * c->max_batch : nullptr;
     P.next_count = more ? cnt + k : nullptr;
-    if (long_h && chain[k] == 3) {  // robots beyond 192 rows go on to the large-problem producer
+    if (pl.long_h && kChain[k] == 3) {  // robots beyond 192 rows go on to the large-problem producer
       P.next_list = c->d_lists + (size_t)3 * c->max_batch;
-      P.next_count = cnt + QMPC_CNT_BIG;
+      P.next_count = cnt + QMPC_CNT_BIGLIST;
+    }
+    if (pl.split[k]) {
+      if (const int rc = run_items(P, kChain[k] == 2 ? 0 : 1, kChain[k], P.list, P.count)) return rc;
+      continue;
     }
     // the first class of the chain: one workgroup per robot; the later ones: one per resident slot, the list
     // is consumed as a queue (no workgroup is dispatched only to find its list entry missing)
-    const bool listed = k > k0;
-    // ---- decoupled path (128- and 192-row classes, exact solve, cold start): sweep kernel -> work items -> engine
-    // kernel -> (rarely) the monolithic kernel on the robots the engine handed back
-    // (automatic: a small batch is latency-bound -- one workgroup per CU either way -- and the one-kernel path has one
-    //  launch and no trip through L2 on it: measured break-even ~300 robots in the 128-row class, below 128 in the
-    //  192-row class.  Decided by the HANDLE's size, not the call's: a robot's result does not depend on the batch it is
-    //  solved in -- the two paths agree to ~1e-14 relative, not bit for bit)
-    const bool big = c->split == 2 || c->max_batch >= (chain[k] == 2 ? 384 : 128);
-    const bool split = c->split && big && (chain[k] == 2 || chain[k] == 3) && !P.admm_mode && !P.ws;
-    if (split) {
-      const int sk = chain[k] == 2 ? 0 : 1;
-      if (const int rc = ensure_split(c, chain[k])) return rc;
-      QmpcParams A = P;
-      A.wk_hinv = c->d_wk_hinv[sk];
-      A.wk_xu = c->d_wk_xu[sk];
-      A.wk_hdr = c->d_wk_hdr[sk];
-      A.wk_order = c->d_wk_order[sk];
-      A.wk_ld = chain[k] == 2 ? 128 : 192;
-      A.wk_cap = c->wk_cap[sk];
-      A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
-      A.wk_block = c->block ? 1 : 0;
-      A.fb_list = c->d_fb_lists + (size_t)sk * c->max_batch;
-      A.fb_count = cnt + 12 + sk;
-      // chunks of consecutive robots (list entries): the sweep kernels run one after the other on one auxiliary stream, every
-      // chunk's engine kernel on another as soon as ITS sweep is done -- beside the next chunk's sweep.  A launch ends
-      // with its slowest robot (60+ iterations when braking): the more chunks, the less of the batch waits behind it
-      int nch = c->chunks > 0 ? c->chunks : 1;
-      if (nch > QMPC_MAX_CHUNKS) nch = QMPC_MAX_CHUNKS;
-      const int per = (batch + nch - 1) / nch;
-      A.wk_ovf = nch > 1 ? nullptr : c->d_wk_ovf[sk];  // (chunks' engine kernels overlap: no shared slices; they hand back instead)
-      if (nch > 1) {
-        if (const int rc = ensure_aux(c)) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_fork, stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-      }
-      for (int ch = 0; ch < nch; ++ch) {
-        const int lo = ch * per, hi = (lo + per < batch) ? lo + per : batch;
-        if (lo >= hi) break;
-        hipStream_t sa = nch > 1 ? c->aux[0] : stream, sb = nch > 1 ? c->aux[1 + (ch & 1)] : stream;
-        A.wk_count = cnt + 16 + 8 * sk + ch;
-        A.wk_qhead = cnt + 32 + 8 * sk + ch;
-        A.wk_bucket = cnt + 64 + QMPC_ORDER_BUCKETS * (8 * sk + ch);
-        A.wk_base = lo;
-        A.rid0 = lo;
-        A.list_hi = hi;
-        A.qhead = listed ? cnt + 48 + 8 * sk + ch : nullptr;
-        A.clear_counts = (!listed && ch == 0) ? cnt_next : nullptr;
-        int grid = hi - lo;
-        if (listed) {
-          const int res = qmpc_resident_sweep(chain[k]);
-          if (res > 0 && res < grid) grid = res;
-        }
-        HIP_TRY(c, qmpc_launch_sweep(chain[k], &A, grid, sa));
-        if (nch > 1) {
-          HIP_TRY(c, hipEventRecord(c->ev_chunk[ch], sa));
-          HIP_TRY(c, hipStreamWaitEvent(sb, c->ev_chunk[ch], 0));
-        }
-        QmpcParams B = A;  // the engine: one robot per workgroup, the chunk's items as a queue
-        B.list = nullptr; B.count = nullptr; B.qhead = nullptr; B.clear_counts = nullptr;
-        B.next_list = nullptr; B.next_count = nullptr;
-        int gb = hi - lo;
-        {
-          const int res = qmpc_engine_resident(chain[k]);
-          if (res > 0 && res < gb) gb = res;
-        }
-        HIP_TRY(c, qmpc_engine_launch(chain[k], &B, gb, sb));
-      }
-      if (nch > 1)
-        for (int a = 0; a < 3; ++a) {  // join: everything after this (hand-backs, the next class, the caller) sees all chunks
-          HIP_TRY(c, hipEventRecord(c->ev_join[a], c->aux[a]));
-          HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_join[a], 0));
-        }
-      QmpcParams F = P;  // robots handed back (event capacity exceeded): the monolithic kernel, list-consuming
-      F.list = A.fb_list; F.count = A.fb_count; F.qhead = cnt + 14 + sk; F.clear_counts = nullptr;
-      F.list_hi = 0x7fffffff;
-      F.next_list = nullptr; F.next_count = nullptr;
-      F.status_or = QMPC_DEV_ST_FALLBACK;
-      if (chain[k] == 3 && c->d_evflags)
-        HIP_TRY(c, hipMemsetAsync(c->d_evflags, c->dbg_pool_busy ? 1 : 0, sizeof(int) * (size_t)c->ev_nslot, stream));
-      int gf = batch;
-      {
-        const int res = qmpc_resident_blocks(chain[k]);
-        if (res > 0 && res < gf) gf = res;
-      }
-      HIP_TRY(c, qmpc_launch(chain[k], &F, gf, stream));
-      continue;
-    }
-    if (chain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
-      HIP_TRY(c, hipMemsetAsync(c->d_evflags, c->dbg_pool_busy ? 1 : 0, sizeof(int) * (size_t)c->ev_nslot, stream));
+    if (kChain[k] == 3 && c->d_evflags)  // no kernel of this handle is in flight on another stream (ordered above)
+      HIP_TRY(c, fill_ints(c->d_evflags, c->ev_nslot, c->dbg_pool_busy ? 1 : 0, stream));
+    P.clear_counts = first ? cnt_next : nullptr;
+    first = false;
     int grid = batch;
     if (listed) {
-      const int res = qmpc_resident_blocks(chain[k]);
+      const int res = qmpc_resident_blocks(kChain[k]);
       if (res > 0 && res < grid) grid = res;
     }
-    HIP_TRY(c, qmpc_launch(chain[k], &P, grid, stream));
+    HIP_TRY(c, qmpc_launch(kChain[k], &P, grid, stream));
   }
-  if (long_h) {
-    // ---- the large problems (192 < n_r <= 432: all feet down beyond 16 segments, a trot beyond 32): H in global memory, block
-    // sweep, the seven-block engine; what that engine cannot hold is REPORTED (the one-kernel path's stage 0 finds no class for
-    // it: QMPC_ST_WS_FULL, zero forces).  Normally the list is empty: two launches that find nothing to do
-    if (const int rc = ensure_split(c, 5)) return rc;
+  if (pl.long_h) {
+    // ---- the large problems (192 < n_r <= 432: all feet down beyond 16 segments, a trot beyond 32): H in global memory,
+    // block sweep, the seven-block engine; what that engine cannot hold is REPORTED.  Normally the list is empty: launches
+    // that find nothing to do
     QmpcParams A = P;
-    A.list = c->d_lists + (size_t)3 * c->max_batch;
-    A.count = cnt + QMPC_CNT_BIG;
-    A.qhead = cnt + QMPC_CNT_BIG + 1;
-    A.clear_counts = nullptr;
     A.next_list = nullptr; A.next_count = nullptr;
-    A.list_hi = 0x7fffffff;
-    A.rid0 = 0;
-    A.wk_hinv = c->d_wk_hinv[2]; A.wk_xu = c->d_wk_xu[2]; A.wk_hdr = c->d_wk_hdr[2]; A.wk_order = c->d_wk_order[2];
-    A.wk_ovf = c->d_wk_ovf[2];
-    A.wk_ld = QMPC_BIG_LD; A.wk_cap = c->wk_cap[2]; A.wk_base = 0;
-    A.wk_kev = c->dbg_engine_events > 0 ? c->dbg_engine_events : (1 << 20);
-    A.wk_block = 0;
-    A.wk_count = cnt + QMPC_CNT_BIG + 2;
-    A.wk_qhead = cnt + QMPC_CNT_BIG + 3;
-    A.wk_bucket = cnt + QMPC_CNT_BIG + 4;
-    A.fb_list = c->d_fb_lists;  // (class 2's hand-back list is not in use at these horizons)
-    A.fb_count = cnt + QMPC_CNT_BIG + 4 + QMPC_ORDER_BUCKETS;
     A.status_or = 0;
-    int gp = batch;
-    {
-      const int res = qmpc_resident_blocks(3);  // (the producer has the 192-row class's footprint: one workgroup per CU)
-      if (res > 0 && res < gp) gp = res;
-    }
-    HIP_TRY(c, qmpc_big_launch(&A, gp, stream));
-    QmpcParams B = A;
-    B.list = nullptr; B.count = nullptr; B.qhead = nullptr;
-    int gb = batch;
-    {
-      const int res = qmpc_engine_resident(5);
-      if (res > 0 && res < gb) gb = res;
-    }
-    HIP_TRY(c, qmpc_engine_launch(5, &B, gb, stream));
-    QmpcParams F = P;  // what the engine handed back: reported by the one-kernel path (no class takes n_r > 192)
-    F.list = A.fb_list; F.count = A.fb_count; F.qhead = cnt + QMPC_CNT_BIG + 5 + QMPC_ORDER_BUCKETS; F.clear_counts = nullptr;
-    F.list_hi = 0x7fffffff;
-    F.next_list = nullptr; F.next_count = nullptr;
-    int gf = batch;
-    {
-      const int res = qmpc_resident_blocks(3);
-      if (res > 0 && res < gf) gf = res;
-    }
-    HIP_TRY(c, qmpc_launch(3, &F, gf, stream));
+    A.clear_counts = nullptr;
+    if (const int rc = run_items(A, 2, 3, c->d_lists + (size_t)3 * c->max_batch, cnt + QMPC_CNT_BIGLIST)) return rc;
   }
   return QMPC_OK;
 }

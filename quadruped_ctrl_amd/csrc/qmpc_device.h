@@ -24,20 +24,30 @@
 #define QMPC_EV_SLICE3 (160 * 320)
 
 // per-call device counters, one set of QMPC_COUNTERS ints (two sets, ping-ponged between consecutive calls; the first
-// kernel of a chain zeroes the NEXT call's set):  [0..2] list lengths of classes 4, 2, 3   [4..6] their queue heads
-// [7] overflow-pool slices handed out   [8,9] work items produced by the sweep kernels of classes 2, 3   [10,11] the
-// engine kernels' queue heads   [12,13] robots handed back to the monolithic kernels   [14,15] their queue heads
-//   chunked launches of the decoupled path (sweep / engine kernels of consecutive robot ranges on separate streams, so
-//   that a chunk's active set runs beside the next chunk's sweep), split class sk = 0 (128 rows) / 1 (192 rows), chunk c < 8:
-//   [16 + 8 sk + c] work items produced   [32 + 8 sk + c] engine queue head   [48 + 8 sk + c] sweep kernel's list queue head
-//   [64 + 16 (8 sk + c) + b] work items in order bucket b (hardest robots first: the engine workgroups take the items
-//   bucket by bucket -- a launch ends with its slowest robot, which must not be the one that started last)
-#define QMPC_MAX_CHUNKS 8
+// kernel of a chain zeroes the NEXT call's set):
+//   [0..2] list lengths of classes 4, 2, 3   [3] list length of the large problems (horizons > 16, n_r > 192)
+//   [4..6] queue heads of the one-kernel list consumers   [7] overflow-pool slices handed out
+//   [8 + sk] robots the engine kernel of item class sk hands back (sk = 0: 128-row class, 1: 192-row class, 2: large
+//   problems)   [12 + sk] queue heads of the launches that take them
+//   [QMPC_CNT_GRP(sk, g)], g = 0 / 1: one GROUP of counters per chunk in flight of item class sk.  The work items of a class
+//   are a bounded pool (qmpc_capi.cpp: ensure_pools); a call with more robots than items runs the class as consecutive
+//   CHUNKS on the caller's stream -- sweep kernel, engine kernel, sweep kernel, ... -- chunk ch on group ch & 1; the engine
+//   kernel of chunk ch zeroes the group chunk ch + 1 is going to use (its previous user, chunk ch - 1, has finished):
+//   [+0] work items produced   [+1] engine queue head   [+2] the sweep kernel's list queue head
+//   [+8 + b] work items in order bucket b (hardest robots first: the engine workgroups take the items bucket by bucket --
+//   a launch ends with its slowest robot, which must not be the one that started last)
 #define QMPC_ORDER_BUCKETS 16
-//   the large problems (horizons > 16, n_r > 192) from QMPC_CNT_BIG: [+0] list length  [+1] the producer's queue head  [+2] work
-//   items produced  [+3] the engine's queue head  [+4 .. +19] order buckets  [+20] robots handed back  [+21] their queue head
-#define QMPC_CNT_BIG (64 + 2 * QMPC_MAX_CHUNKS * QMPC_ORDER_BUCKETS)
-#define QMPC_COUNTERS (QMPC_CNT_BIG + 8 + QMPC_ORDER_BUCKETS)
+#define QMPC_GRP_INTS 32
+#define QMPC_CNT_BIGLIST 3
+#define QMPC_CNT_FB 8
+#define QMPC_CNT_FBQ 12
+#define QMPC_CNT_GRP(sk, g) (64 + QMPC_GRP_INTS * (2 * (sk) + (g)))
+#define QMPC_COUNTERS (64 + QMPC_GRP_INTS * 6)
+// work items per class (the pool is min(max_batch, this)): 128-row class 128 KiB each, 192-row class 288 KiB, large
+// problems 1.53 MiB -- 0.5 / 0.84 / 1.5 GiB at most, whatever max_batch is
+#define QMPC_ITEMS_C2 4096
+#define QMPC_ITEMS_C3 3072
+#define QMPC_ITEMS_BIG 1024
 
 // decoupled path: a sweep workgroup (or the long-horizon producer) leaves its robot's explicit inverse,
 // unconstrained minimiser and stance list in a work item; single-robot engine workgroups consume the items
@@ -113,7 +123,8 @@ struct QmpcParams {
   int* wk_count;
   int* wk_qhead;
   int wk_ld, wk_cap;
-  int wk_base;  // first work item of this launch's chunk (items wk_base .. wk_base + *wk_count - 1)
+  int wk_base;  // first work item of this launch's chunk (items wk_base .. wk_base + *wk_count - 1; 0: the chunks of a call reuse the pool one after the other)
+  int* wk_zero;  // engine kernel: the counter group (QMPC_GRP_INTS ints) of the NEXT chunk, zeroed by workgroup 0 (nullptr: none)
   // order in which the engine workgroups take the items: QMPC_ORDER_BUCKETS lists of item indices, bucket b of this chunk
   // at wk_order[b * wk_cap + wk_base ...], wk_bucket[b] entries; bucket 0 = most rows violated at x_u
   int* wk_order;

@@ -1299,6 +1299,8 @@ __global__ __launch_bounds__(64 * NW, 2) void qmpc_engine_kernel(const QmpcParam
   using C = ECfg<RE, KQ, SQ, NW, MAXL, MAXE>;
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_esmem[];
   ESmem<C>& S = *reinterpret_cast<ESmem<C>*>(qmpc_esmem);
+  // the counter group of the NEXT chunk of this class (its previous user, the chunk before this one, has finished)
+  if (blockIdx.x == 0 && P.wk_zero && threadIdx.x < QMPC_GRP_INTS) P.wk_zero[threadIdx.x] = 0;
   const int nitems = *P.wk_count;
   if ((int)blockIdx.x >= nitems) return;  // uniform
   static_assert(sizeof(QmpcParams) % 4 == 0 && sizeof(QmpcParams) / 4 <= 64 * NW, "parameter block copy");

@@ -601,7 +601,15 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     } else if (P.next_list) {
       if (tid == 0) {
         const int slot = atomicAdd(P.next_count, 1);
-        P.next_list[slot] = rid;
+        // (a list holds one entry per robot of the call at most; a slot beyond that means the host's counters are
+        //  corrupt -- report the robot instead of writing past the list)
+        if (slot < P.batch) {
+          P.next_list[slot] = rid;
+        } else {
+          P.status[rid] = QMPC_DEV_ST_WS_FULL;
+          if (P.iters) P.iters[rid] = 0;
+          for (int k = 0; k < 12; ++k) P.grf[(size_t)rid * 12 + k] = 0.f;
+        }
       }
     } else {
       // larger than the caller's size hint allows and no class left to take it: reported, with
@@ -671,6 +679,21 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   }
   __syncthreads();  // ---- barrier 2
   QMPC_TICK(2);
+  if constexpr (PHA) {
+    // (the pool of work items is bounded and the host never launches more robots per chunk than it holds; an index
+    //  beyond it means corrupt counters: the robot is reported, nothing is written out of bounds)
+    if (S.evslot - P.wk_base >= P.wk_cap) {
+      if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
+      if (cmdm && P.f_ff && tid < 12) P.f_ff[(size_t)rid * 12 + tid] = 0.f;
+      if (tid == 0) {
+        P.status[rid] = QMPC_DEV_ST_WS_FULL;
+        if (P.iters) P.iters[rid] = 0;
+        if (cmdm) cmd_finish_state();
+      }
+      __syncthreads();
+      return false;
+    }
+  }
 
 #ifdef QMPC_BIG_STAMP  // (profiling build, tools/big_phase.py: shader-clock stamps of block step QMPC_BIG_STAMP and of the stages around the sweep)
 #define QMPC_BIG_TICK(k) do { if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); } while (0)
@@ -3041,7 +3064,8 @@ template <int RB, bool CMD, bool LISTED = false>
 __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES_A) void qmpc_sweep_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
-  // (a launch covers one CHUNK of the class: robots / list entries rid0 .. ; the chunks of a call run on separate streams)
+  // (a launch covers one CHUNK of the class: robots / list entries rid0 .. list_hi - 1, at most as many as the class has work items;
+  //  the chunks of a call run one after the other on the caller's stream)
   if constexpr (!LISTED) {
     if (blockIdx.x == 0 && P.clear_counts)
       for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;
@@ -3075,9 +3099,11 @@ template <bool CMD>
 __global__ __launch_bounds__(Cfg<3>::NT, Cfg<3>::MIN_WAVES) void qmpc_big_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<3>& S = *reinterpret_cast<Smem<3>*>(qmpc_smem);
-  const int nlist = *P.count;
-  if ((int)blockIdx.x >= nlist) return;  // uniform
-  for (int idx = (int)blockIdx.x;;) {
+  // (a launch covers one CHUNK of the list: entries rid0 .. list_hi - 1, at most as many as there are work items)
+  int nlist = *P.count;
+  nlist = nlist < P.list_hi ? nlist : P.list_hi;
+  if (P.rid0 + (int)blockIdx.x >= nlist) return;  // uniform
+  for (int idx = P.rid0 + (int)blockIdx.x;;) {
     const int rid = P.list[idx];
     int tid1 = (int)threadIdx.x;
     asm volatile("" : "+v"(tid1));
@@ -3088,7 +3114,7 @@ __global__ __launch_bounds__(Cfg<3>::NT, Cfg<3>::MIN_WAVES) void qmpc_big_kernel
     const QmpcParams& PK = *(const QmpcParams*)pk;
     solve_one<3, true, CMD, false, false, true, true>(rid, tid1, S, PK);
     __syncthreads();
-    if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+    if (threadIdx.x == 0) S.qnext = P.rid0 + (int)gridDim.x + atomicAdd(P.qhead, 1);
     __syncthreads();
     idx = S.qnext;
     if (idx >= nlist) break;  // uniform

@@ -29,9 +29,10 @@ def has_gpu():
         return False
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture
 def mpc_factory():
-    """GPU solver factory; HIP extension must be present (no fallback)."""
+    """GPU solver factory; HIP extension must be present (no fallback).  Function-scoped: a handle owns every device
+    pool its horizon can reach from qmpc_setup on (hundreds of MB at long horizons) -- freed when the test ends."""
     from quadruped_ctrl_amd.binding import BatchedConvexMPC
 
     made = []

@@ -1,0 +1,44 @@
+"""Run by tests/test_gpu_hardening.py::test_reference_shim_refuses_jcqp_full_problem_at_long_horizons in a process of its
+own (the shim's state is process-global): use_jcqp = 1 at horizon 20 through the reference's six symbols."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quadruped_ctrl_amd import workloads as W  # noqa: E402
+
+lib = C.CDLL(os.path.join(ROOT, "quadruped_ctrl_amd", "libconvexmpc_shim.so"))
+lib.setup_problem.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double]
+lib.update_solver_settings.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+lib.get_solution.restype = C.c_double
+lib.get_solution.argtypes = [C.c_int]
+fp = C.POINTER(C.c_float)
+lib.update_problem_data_floats.argtypes = [fp, fp, fp, fp, fp, C.c_float, fp, fp, C.c_float, C.POINTER(C.c_int)]
+b = W.make_long_horizon(1, 20, "stand")
+h = 20
+arr = lambda k: np.ascontiguousarray(b[k][0], np.float32)
+p, v, q, w, r, wt, tr = (arr(k) for k in ("p", "v", "q", "w", "r", "weights", "traj"))
+gait = np.ascontiguousarray(b["gait"][0], np.int32)
+ptr = lambda a: a.ctypes.data_as(fp)
+
+def cycle(use_jcqp):
+    lib.setup_problem(b["dt"], h, b["mu"], b["f_max"])        # (the reference's caller repeats it every cycle)
+    lib.update_solver_settings(10000, 1e-7, 1e-8, 1.5, 0.1, use_jcqp)
+    lib.update_problem_data_floats(ptr(p), ptr(v), ptr(q), ptr(w), ptr(r), C.c_float(float(b["yaw"][0])), ptr(wt), ptr(tr),
+                                   C.c_float(float(b["alpha"][0])), gait.ctypes.data_as(C.POINTER(C.c_int)))
+    return lib.qmpc_shim_last_status(), np.array([lib.get_solution(i) for i in range(12)])
+
+st0, f0 = cycle(0.0)
+assert st0 >= 0 and (st0 & 47) == 0 and np.abs(f0).max() > 1.0
+for _ in range(2):
+    st1, f1 = cycle(1.0)
+    assert st1 == -3 and not f1.any()                          # QMPC_SHIM_ERR_SETTINGS, zeros
+    st2, f2 = cycle(0.0)
+    assert st2 == st0 and np.array_equal(f2, f0)
+
+
+
+print("SHIM-JCQP-OK")

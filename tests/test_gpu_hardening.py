@@ -1,0 +1,198 @@
+"""GPU suite (-m gpu): the host side of the C ABI under conditions a long-running caller meets --
+bounded device memory whatever max_batch is, no allocation inside a solve call (hipGraph capture and replay),
+a refused call followed by a good one, batches larger than the work-item pools (chunked classes).
+
+Reference behaviour concerned: the reference keeps ONE robot's matrices in file-scope globals and re-allocates them in
+every setup_problem (SolverMPC.cpp:127-224); the batched handle owns pools instead, and these tests pin their size and
+lifetime."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from quadruped_ctrl_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_bytes():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]  # hipMemGetInfo: free bytes of the device, whoever allocated
+
+
+@pytest.mark.parametrize("h", [14, 36])
+def test_device_memory_is_bounded_for_a_65536_robot_handle(h):
+    """the work items used to be sized by max_batch (19 GB at h = 14, 105 GB beyond 16 for a 65 536-robot
+    handle) and allocated inside the first solve.  Now every pool is bounded and allocated by qmpc_setup: the handle stays
+    under 4 GB, and solves (more robots than the pools hold items: chunked classes) do not change the device's free memory."""
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC
+    import torch
+    torch.cuda.init()
+    before = _free_bytes()
+    m = BatchedConvexMPC(0, max_batch=65536, max_horizon=36)
+    m.setup(0.026, h, 0.4, 120.0)
+    used = before - _free_bytes()
+    print(f"handle for 65536 robots at h={h}: {used / 2**30:.2f} GiB of device memory")
+    assert used < 4 * 2**30
+    # all feet down: every robot goes through the work items (192-row class at h = 14: 3072 items; large problems at
+    # h = 36: 1024 items) -- more robots than items
+    B = 3500 if h == 14 else 1200
+    b = W.make_standing(B, h) if h == 14 else W.make_long_horizon(B, h, "stand")
+    d = m.upload(b)
+    o = m.alloc_outputs(B, full=False)
+    inp, out = m.make_args(d, o)
+    m.solve_async(B, inp, out)
+    f1 = _free_bytes()
+    m.solve_async(B, inp, out)
+    f2 = _free_bytes()
+    assert f1 == f2, (f1, f2)
+    st = o["status"].cpu().numpy()
+    assert ((st & 47) == 0).all(), np.unique(st)
+    # the same robots in two calls that fit the pools: bit-identical forces (a robot's result depends on nothing but
+    # its own record, whatever chunk it lands in)
+    whole = o["grf"].cpu().numpy().copy()
+    half = B // 2
+    parts = []
+    for lo, hi in ((0, half), (half, B)):
+        sub = {k: (v[lo:hi] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in b.items()}
+        sub["batch"] = hi - lo
+        parts.append(m.solve(sub)["grf"])
+    assert np.array_equal(np.concatenate(parts), whole)
+    held = before - _free_bytes()
+    m.close()
+    torch.cuda.synchronize()
+    # the handle's pools are given back (what remains is torch's cache of this test's input / output tensors)
+    assert held - (before - _free_bytes()) > used - 64 * 2**20
+
+
+@pytest.mark.parametrize("name", ["trot_h10", "trot_h16", "random_contacts_h10", "standing_h10_decoupled",
+                                  "standing_h14_decoupled", "stand_h20_large"])
+def test_solve_is_graph_capturable(name):
+    """qmpc_solve only enqueues kernels on the caller's stream: it can be captured into a hipGraph and
+    replayed.  Classes 1 and 4 (trot h = 10 / 16), the 64 -> 96 -> 128-row chain (random contact tables), the decoupled
+    path of the 128- and 192-row classes, and the large-problem path.  50 replays of ONE captured call, every replay's
+    outputs bit-identical to the eager call, eager calls interleaved (a captured call uses a counter set of its own,
+    cleared by a small kernel node in front of its kernels -- a captured memset node writes garbage on replay with ROCm 7.2: it neither depends on nor disturbs the two sets eager calls
+    ping-pong between)."""
+    import torch
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC
+    mk = {"trot_h10": lambda: W.make_config(1, batch=512), "trot_h16": lambda: W.make_config(3, batch=256),
+          "random_contacts_h10": lambda: W.make_config(4, batch=768),
+          "standing_h10_decoupled": lambda: W.make_standing(400, 10),
+          "standing_h14_decoupled": lambda: W.make_standing(160, 14),
+          "stand_h20_large": lambda: W.make_long_horizon(48, 20, "stand")}[name]
+    b = mk()
+    B, h = b["batch"], b["horizon"]
+    m = BatchedConvexMPC(0, max_batch=B, max_horizon=max(16, h))
+    m.setup(b["dt"], h, b["mu"], b["f_max"])
+    if "decoupled" in name:
+        m.set_split(2)
+    d = m.upload(b)
+    o = m.alloc_outputs(B, full=True)
+    inp, out = m.make_args(d, o)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        m.solve_async(B, inp, out, stream=s)   # eager, on the stream the capture will use
+    s.synchronize()
+    eager = {k: o[k].clone() for k in ("grf", "soln", "status", "iters")}
+    assert ((eager["status"].cpu().numpy() & 47) == 0).all()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):       # (global capture mode: a hipMalloc / synchronisation in here fails the capture)
+        m.solve_async(B, inp, out, stream=s)
+    for rep in range(50):
+        for k in ("grf", "soln"):
+            o[k].zero_()
+        o["status"].fill_(-1)
+        g.replay()
+        if rep % 7 == 3:                       # an eager call between replays (same stream order)
+            torch.cuda.synchronize()
+            m.solve_async(B, inp, out)
+        torch.cuda.synchronize()
+        for k in ("grf", "soln", "status", "iters"):
+            assert torch.equal(o[k], eager[k]), (k, rep)
+    # and an eager call after the replays still finds its counters in order
+    m.solve_async(B, inp, out)
+    torch.cuda.synchronize()
+    for k in ("grf", "soln", "status", "iters"):
+        assert torch.equal(o[k], eager[k]), k
+    m.close()
+
+
+def test_refused_call_then_good_call():
+    """a call that is refused must not move the handle's call counter -- the counter sets ping-pong
+    and each call's first kernel clears the NEXT call's set; a refused call that took a set used to leave the following
+    call on stale list lengths and queue heads (out-of-bounds work items with max_batch = 1).  use_jcqp = 1 at a horizon
+    above 16 is refused by qmpc_settings_jcqp / qmpc_setup now, never inside a solve; sequences of good and refused
+    calls give the same answers as good calls alone."""
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC, QmpcError
+    b = W.make_long_horizon(1, 20, "stand")      # n_r = 240: the large-problem path, one work item
+    m = BatchedConvexMPC(0, max_batch=1, max_horizon=36)
+    m.setup(b["dt"], 20, b["mu"], b["f_max"])
+    first = m.solve(b, full=True)
+    assert (first["status"] & 47) == 0 and np.abs(first["grf"]).max() > 1.0
+    for _ in range(3):
+        with pytest.raises(QmpcError):
+            m.settings_jcqp(1)                     # refused: the handle is set up for a horizon above 16
+        again = m.solve(b, full=True)             # still the exact solve, same counters
+        assert np.array_equal(again["soln"], first["soln"]) and again["status"] == first["status"]
+    # the other order: mode 1 selected at a short horizon, then a long horizon is asked for
+    m.setup(b["dt"], 10, b["mu"], b["f_max"])
+    m.settings_jcqp(1)
+    with pytest.raises(QmpcError):
+        m.setup(b["dt"], 20, b["mu"], b["f_max"])
+    m.settings_jcqp(0)
+    m.setup(b["dt"], 20, b["mu"], b["f_max"])
+    assert np.array_equal(m.solve(b, full=True)["soln"], first["soln"])
+    # argument errors in between (batch beyond max_batch) do not disturb anything either
+    two = W.make_long_horizon(2, 20, "stand")
+    for _ in range(3):
+        with pytest.raises(QmpcError):
+            m.solve(two)
+        assert np.array_equal(m.solve(b, full=True)["soln"], first["soln"])
+    # use_jcqp = 2 at a long horizon: robots beyond 192 rows are REPORTED, not solved by another method
+    m.settings_jcqp(2)
+    r2 = m.solve(b, full=True)
+    assert r2["status"][0] & 8 and not r2["grf"].any()
+    m.settings_jcqp(0)
+    assert np.array_equal(m.solve(b, full=True)["soln"], first["soln"])
+    m.close()
+
+
+def test_reference_shim_refuses_jcqp_full_problem_at_long_horizons():
+    """The six-symbol shim (include/convexMPC_interface.h): update_solver_settings(..., use_jcqp = 1) at a horizon above
+    16 makes the next update_problem_data_floats a refused call -- QMPC_SHIM_ERR_SETTINGS, get_solution reads 0 -- and
+    going back to use_jcqp = 0 gives the first answer again (the sequence of ADVICE r3's first finding).  In a process
+    of its own: the shim's state is process-global like the reference's (convexMPC_interface.cpp:13-20)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_jcqp_long_horizon.py")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and "SHIM-JCQP-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_more_robots_than_work_items_same_results(mpc_factory):
+    """A class with fewer work items than robots runs in consecutive chunks on the caller's stream (producer, engine,
+    producer, ...; counter groups ping-ponged, the engine kernel of a chunk clears the next chunk's group).  Forced here
+    with qmpc_set_chunks on batches that would fit: 128-row class first in the chain (robot ranges), 128-row class behind
+    the 64- / 96-row classes (list ranges), and the large problems.  Bit-identical to the single-chunk call, also when
+    the chunk count does not divide the batch and when chunks come out empty."""
+    cases = [("standing h10 (class first in chain)", W.make_standing(450, 10), True),
+             ("random contact tables h10 (list behind two classes)", W.make_config(4, batch=1500), False),
+             ("all feet down h20 (large problems)", W.make_long_horizon(40, 20, "stand"), False)]
+    for name, b, first in cases:
+        m = mpc_factory(b)
+        m.set_split(2)
+        if first:
+            m.set_min_stance(40)
+        base = m.solve(b, full=True)
+        assert ((base["status"] & 47) == 0).all(), name
+        for nch in (2, 3, 7, 33):
+            m.set_chunks(nch)
+            res = m.solve(b, full=True)
+            for k in ("status", "iters", "soln", "grf"):
+                assert np.array_equal(res[k], base[k]), (name, nch, k)
+        m.set_chunks(0)
+        assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])

@@ -1058,9 +1058,9 @@ def test_decoupled_engine_hands_back_what_it_cannot_hold(mpc_factory):
 
 
 def test_decoupled_path_chunked_launches_same_results(mpc_factory):
-    """qmpc_set_chunks (measured: not faster, default 1) runs the sweep / engine kernels of consecutive robot ranges on
-    auxiliary streams: every chunk has its own item counter, order buckets and queue head, and its engine kernel must not
-    share overflow slices with the neighbour's.  Same robots, same kernels: bit-identical results, whatever the split."""
+    """qmpc_set_chunks (test hook) runs the sweep / engine kernels of consecutive robot ranges one after the other on the
+    caller's stream, the way a batch larger than the work-item pool is processed: counter groups ping-ponged between
+    chunks, the pool and the overflow slices reused.  Same robots, same kernels: bit-identical results, whatever the split."""
     b = W.make_standing(700, 10)
     m = mpc_factory(b)
     m.set_split(True)
@@ -1330,6 +1330,31 @@ def test_bench_two_ranks_dry_run():
     assert 0 < g["value"] <= 1.5 * d["value"]
 
 
+def test_bench_eight_ranks_config4_dry_run():
+    """the command the driver's 8-GPU scaling run issues for configs[4] -- `--gpus 8 --config 4` -- as
+    eight ranks sharing this box's GPU over gloo (tiny --batch): the 8-rank rendezvous, the shard arithmetic (rank r
+    takes robots [r B, (r + 1) B) of the 8 B generated), the gather of all ranks' rows and the per-rank device records
+    have run once before hardware does it.  On the 8-GPU node the same code runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, QMPC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "8", "--steps", "5", "--warmup", "2", "--settle", "0", "--repeats", "3", "--config", "4",
+                          "--batch", "96"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["batch_per_gpu"] == 96 and d["config"]["horizon"] == 10
+    assert d["config"]["failed"] == 0 and d["repeats"] == 3
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    assert d["gather"]["gathered_rows_match_local_on_every_rank"] is True and d["gather"]["bytes_per_step"] == 8 * 96 * 48
+    assert len(d["per_rank"]["elapsed_s"]) == 8
+    assert [r["rank"] for r in d["rank_devices"]] == list(range(8)) and d["world_size"] == 8
+    assert all(r["device_name"] for r in d["rank_devices"]) and d["distinct_devices"] >= 1
+
+
 def test_bench_two_ranks_config3_baseline_split():
     """`bench.py --gpus N --config 3` takes BASELINE's batch split (configs[3]: 16384 robots over 4 GPUs = 4096 per
     rank, horizon 16) whatever N is launched; two ranks over gloo on this box's GPU, real solver on every rank."""
@@ -1521,8 +1546,12 @@ def _sparse_exact(b, i):
 
 @pytest.mark.parametrize("mk", [lambda: W.make_config(2, batch=10), lambda: W.make_config(4, batch=10),
                                 lambda: W.make_trot(6, 16), lambda: W.make_standing(3, 14, calm=True),
-                                lambda: W.make_long_horizon(4, 24, "trot"), lambda: W.make_long_horizon(4, 36, "bound")],
-                         ids=["mixed_h10", "stairs_random_h10", "trot_h16", "standing_h14", "trot_h24", "bound_h36"])
+                                lambda: W.make_long_horizon(4, 24, "trot"), lambda: W.make_long_horizon(4, 36, "bound"),
+                                # beyond 192 rows: the large-problem path (n_r = 216 / 288 / 432)
+                                lambda: W.make_long_horizon(3, 36, "trot"), lambda: W.make_long_horizon(3, 24, "stand"),
+                                lambda: W.make_long_horizon(2, 36, "stand")],
+                         ids=["mixed_h10", "stairs_random_h10", "trot_h16", "standing_h14", "trot_h24", "bound_h36",
+                              "large_trot_h36", "large_stand_h24", "large_stand_h36"])
 def test_sparse_formulation_model(mk, mpc_factory):
     """QMPC_MODEL_SPARSE returns the exact minimiser of the reference's SPARSE formulation
     (SparseCMPC.cpp:31-73 with SparseCMPC_Math.cpp's discretisation), with SparseCMPC's own parameters
