@@ -86,6 +86,8 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
+        # (development only: QMPC_LIB names a variant build of the same library -- tools/build_variant.sh; unset in production)
+        LIB_PATH = os.environ.get("QMPC_LIB") or globals()["LIB_PATH"]
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP extension first "

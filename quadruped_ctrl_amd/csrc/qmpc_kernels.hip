@@ -112,6 +112,51 @@ __device__ __forceinline__ void fmac4_rowbcast(double (&a)[16], double c, double
       : "v"(c), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3));
 }
 
+// p[0 .. N-1] += c[lane J0 + k of this lane's row] * u for N = 2, 4 or 8 consecutive columns given by pointer
+template <int J0, int N>
+__device__ __forceinline__ void fmacn_rowbcast(double* p, double c, double u) {
+  static_assert(N == 2 || N == 4 || N == 8, "block of 2, 4 or 8 columns");
+  if constexpr (N == 2) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(p[0]), "+v"(p[1])
+        : "v"(c), "v"(u), "n"(J0), "n"(J0 + 1));
+  } else if constexpr (N == 4) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])
+        : "v"(c), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %8, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %8, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %8, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %8, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %8, %9 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %8, %9 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, %8, %9 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %7, %8, %9 row_newbcast:%17 row_mask:0xf bank_mask:0xf"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])
+        : "v"(c), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3), "n"(J0 + 4), "n"(J0 + 5), "n"(J0 + 6), "n"(J0 + 7));
+  }
+}
+// ... for the columns LO .. HI-1 of a group (g points at the group's first column; LO, HI even): aligned blocks of 8 / 4 / 2
+template <int LO, int HI>
+__device__ __forceinline__ void fmac_range_rowbcast(double* g, double c, double u) {
+  if constexpr (LO < HI) {
+    constexpr int B = (LO % 8 == 0 && HI - LO >= 8) ? 8 : ((LO % 4 == 0 && HI - LO >= 4) ? 4 : 2);
+    fmacn_rowbcast<LO, B>(g + LO, c, u);
+    fmac_range_rowbcast<LO + B, HI>(g, c, u);
+  }
+}
+
 // the same for eight accumulators (the 24-column groups of class 4: 16 + 8)
 __device__ __forceinline__ void fmac8_rowbcast(double (&a)[8], double c, double u) {
   asm volatile(
@@ -255,6 +300,21 @@ struct Smem {
   do {                                                 \
     if (dbg_clk && tid == 0) dbg_clk[(k)] = clock64(); \
   } while (0)
+
+// profiling build (-DQMPC_SWEEP_STAMP=<k0>): shader-clock stamps INSIDE the sweep step that starts at pivot k0, taken by thread 0
+// and stored in row rid + batch of the clock buffer (which the tool allocates twice as long), slots 0..7: tools/sweep_step_phase.py
+#ifdef QMPC_SWEEP_STAMP
+#define QMPC_STEP_TICK(k, dep)                                                                            \
+  do {                                                                                                    \
+    if (PK.dbg_clk && tid == 0 && k0 == QMPC_SWEEP_STAMP) {                         \
+      double dep__ = (dep);                                                                               \
+      asm volatile("" ::"v"(dep__));                                                                      \
+      PK.dbg_clk[(size_t)(rid + PK.batch) * 16 + (k)] = clock64();                                    \
+    }                                                                                                     \
+  } while (0)
+#else
+#define QMPC_STEP_TICK(k, dep) do { } while (0)
+#endif
 
 // CMD selects where the input record comes from: false = loaded (qmpc_solve), true =
 // generated in stage 0 from the controller command (qmpc_solve_commands).
@@ -1380,8 +1440,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     // single-wave issue rate (same values, same operations: results are bit-identical).
     auto lane_next = [](double x) __attribute__((always_inline)) {  // value of lane + 1 (DPP row_shl:1)
       const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-      const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x101, 0xf, 0xf, false);
-      const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x101, 0xf, 0xf, false);
+      // (bound_ctrl: no `old` operand to initialise -- two moves less per value on the step's critical chain)
+      const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x101, 0xf, 0xf, true);
+      const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x101, 0xf, 0xf, true);
       return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     };
     auto publish_pinv = [&](double d0, double e, double d1p, int par) __attribute__((always_inline)) {
@@ -1390,10 +1451,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       const double det = __builtin_fma(d0, d1p, -e * e);
       const double idet = fast_rcp(det);
       double* pv = Sw.ubuf[par][0];
-      pv[0] = d1p * idet;  // +-entries of P^-1: i11, i01, i00
-      pv[1] = e * idet;
-      pv[2] = d0 * idet;
-      pv[3] = (!(d0 > 0.0) | !(det > 0.0)) ? 1.0 : 0.0;
+      st2(pv, d1p * idet, e * idet);  // +-entries of P^-1: i11, i01, i00
+      // ... and ONE number whose sign says whether both pivots were positive (a NaN fails the readers' test as well)
+      st2(pv + 2, d0 * idet, (d0 < det) ? d0 : det);  // (ordered compare: a NaN determinant is what gets stored)
     };
     if (c == 0) {
       Sw.colbuf[0][0][i] = a[0];
@@ -1417,16 +1477,36 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         const int k0 = kb * CW + r0, k1 = k0 + 1;  // k1 == n: identity padding column, a no-op pivot
         if (k0 < n) {
           const int m = k0 >> 1;
+          QMPC_STEP_TICK(0, 0.0);
           const double* cb0 = Sw.colbuf[m & 1][0];
           const double* cb1 = Sw.colbuf[m & 1][1];
           const double* pv = Sw.ubuf[m & 1][0];
           const double c0i = cb0[i], c1i = cb1[i];
           const double i11 = pv[0], i01 = pv[1], i00 = pv[2];  // +-entries of P^-1
-          notpd |= (pv[3] != 0.0);
+          // (the pivot-column values of the next pair's group: loaded HERE, with the row's own entries -- one LDS round
+          //  trip for the step's critical chain; further down they would sit behind the pivot rows' branch, whose memory
+          //  clobber keeps loads from moving up)
+          constexpr bool TAIL8 = (CW % 16 == 8);
+          constexpr int NG = (CW + 15) / 16;                         // groups (the last one 8 wide when TAIL8)
+          constexpr int GN = (rn0 / 16 < NG) ? rn0 / 16 : NG - 1;    // group of the next pivot pair
+          constexpr bool GN_TAIL = TAIL8 && GN == NG - 1;
+          constexpr int GN0 = 16 * GN, JN = rn0 - GN0, WN = GN_TAIL ? 8 : 16;
+          // ... and of every other group: ALL the step's LDS loads are in flight together (they used to be three round
+          // trips in a row -- row entries, next pair's group, the other groups -- in EVERY wave: 0.35 k of a 1.2 k-cycle step)
+          double cvg0[NG], cvg1[NG];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const bool tl = TAIL8 && g == NG - 1;
+            cvg0[g] = cb0[c * CW + 16 * g + (tl ? (lane & 7) : (lane & 15))];
+            cvg1[g] = cb1[c * CW + 16 * g + (tl ? (lane & 7) : (lane & 15))];
+          }
+          const double cvn0 = cvg0[GN], cvn1 = cvg1[GN];
+          notpd |= !(pv[3] > 0.0);
           // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i ; kept NEGATED (the
           // update is a += c * (-F): the sign goes into the fma instead of into extra instructions)
           const double nf0 = __builtin_fma(-i11, c0i, i01 * c1i);
           const double nf1 = __builtin_fma(-i00, c1i, i01 * c0i);
+          QMPC_STEP_TICK(1, nf0 + nf1);
           const bool p0 = (i == k0), p1 = (i == k1);
           // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j).  Two lanes of ONE
           // wave: a branch the other waves skip, instead of eight selects in every lane of every wave (the step is
@@ -1437,33 +1517,15 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             nu0 = nf0 + (p0 ? i11 : -i01);
             nu1 = nf1 + (p0 ? -i01 : i00);
           }
-          // the CW pivot-column values of this column group, 16 per register (one per
-          // lane of a row), broadcast inside the DPP fmac -- see fmac16_rowbcast
-          auto upd16 = [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
-            const double cv0 = cb0[c * CW + 16 * g + (lane & 15)];
-            const double cv1 = cb1[c * CW + 16 * g + (lane & 15)];
-            double(&ag)[16] = *reinterpret_cast<double(*)[16]>(&a[16 * g]);
-            fmac16_rowbcast(ag, cv0, nu0);
-            fmac16_rowbcast(ag, cv1, nu1);
-          };
-          auto upd8 = [&]() __attribute__((always_inline)) {  // class 4: the last eight columns of the group
-            constexpr int G8 = CW - 8;
-            const double cv0 = cb0[c * CW + G8 + (lane & 7)];
-            const double cv1 = cb1[c * CW + G8 + (lane & 7)];
-            double(&ag)[8] = *reinterpret_cast<double(*)[8]>(&a[G8]);
-            fmac8_rowbcast(ag, cv0, nu0);
-            fmac8_rowbcast(ag, cv1, nu1);
-          };
-          // The sixteen (eight) columns that hold the NEXT pivot pair go first: their owner publishes the pair and
-          // the inverse of its 2x2 block while everybody, itself included, still updates the other columns -- the
-          // determinant / reciprocal / LDS-store chain leaves the critical path of the step (the order in which a
-          // thread updates its independent columns does not change a single bit of the result)
-          constexpr bool TAIL8 = (CW % 16 == 8);
-          constexpr bool NEXT_IN_TAIL = TAIL8 && (rn0 >= CW - 8);
-          constexpr int GNX = NEXT_IN_TAIL ? -1 : rn0 / 16;
-          if constexpr (NEXT_IN_TAIL) upd8();
-          else upd16(std::integral_constant<int, (GNX < 0 ? 0 : GNX)>{});
+          // The thread's columns in groups of 16 (class 4: 16 + 8): a group's pivot-column values are held one per lane of
+          // a row of 16 (8) and broadcast inside the DPP fmac.  Only the TWO columns of the next pivot pair are updated
+          // before their owner publishes them and the inverse of their 2 x 2 block -- four fmacs on the step's critical
+          // chain instead of the whole group's 32 (the step of these classes is bound by that chain, not by issue:
+          // tools/sweep_step_phase.py) -- then everybody, the owner included, updates the rest; the order in which a thread
+          // updates its independent columns does not change a single bit of the result
+          fmacn_rowbcast<JN, 2>(&a[rn0], cvn0, nu0);
+          fmacn_rowbcast<JN, 2>(&a[rn0], cvn1, nu1);
+          QMPC_STEP_TICK(2, a[rn0] + a[rn1]);
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
             Sw.colbuf[(m + 1) & 1][0][i] = a[rn0];
@@ -1471,11 +1533,31 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             const double e_n = lane_next(a[rn0]), d1_n = lane_next(a[rn1]);  // A[k1'][k0'], A[k1'][k1'] of the next pair
             if (i == k0 + 2) publish_pinv(a[rn0], e_n, d1_n, (m + 1) & 1);
           }
+          QMPC_STEP_TICK(3, 0.0);
           __builtin_amdgcn_sched_barrier(0);
-          StaticFor<0, CW / 16>::run([&](auto gc) __attribute__((always_inline)) {
-            if constexpr (decltype(gc)::value != GNX) upd16(gc);
+          // the rest of the next pair's group: both pivot columns over the columns before the pair, then after it (the
+          // same two updates, in the same order, for every element as fmac16 + fmac16)
+          fmac_range_rowbcast<0, JN>(&a[GN0], cvn0, nu0);
+          fmac_range_rowbcast<JN + 2, WN>(&a[GN0], cvn0, nu0);
+          fmac_range_rowbcast<0, JN>(&a[GN0], cvn1, nu1);
+          fmac_range_rowbcast<JN + 2, WN>(&a[GN0], cvn1, nu1);
+          StaticFor<0, NG>::run([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g != GN) {
+              constexpr bool TAIL = TAIL8 && g == NG - 1;
+              const double cv0 = cvg0[g], cv1 = cvg1[g];
+              if constexpr (TAIL) {
+                double(&ag)[8] = *reinterpret_cast<double(*)[8]>(&a[16 * g]);
+                fmac8_rowbcast(ag, cv0, nu0);
+                fmac8_rowbcast(ag, cv1, nu1);
+              } else {
+                double(&ag)[16] = *reinterpret_cast<double(*)[16]>(&a[16 * g]);
+                fmac16_rowbcast(ag, cv0, nu0);
+                fmac16_rowbcast(ag, cv1, nu1);
+              }
+            }
           });
-          if constexpr (TAIL8 && !NEXT_IN_TAIL) upd8();
+          QMPC_STEP_TICK(4, a[0] + a[CW - 1] + a[CW / 2]);
           if (c == kb) {
             // pivot columns <- F, pivot block <- -P^-1
             a[r0] = -nf0;
@@ -1487,6 +1569,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             }
           }
           __syncthreads();
+          QMPC_STEP_TICK(5, 0.0);
         }
       });
     }
