@@ -53,12 +53,9 @@ void update_x_drag(float x_drag);
  * -1 = never solved; other negative values = the call was refused and get_solution reads 0:
  *   QMPC_SHIM_ERR_SETUP     setup_problem rejected (horizon beyond QMPC_MAX_HORIZON, mu / dt <= 0, no device)
  *                           or update_problem_data* without an accepted setup_problem
- *   QMPC_SHIM_ERR_SETTINGS  update_solver_settings values unusable for the selected use_jcqp (e.g. rho <= 0), or
- *                           use_jcqp = 1 (JCQP on the full 12 h-variable problem, SolverMPC.cpp:400-414) at a horizon
- *                           above 16: the reference runs it at any horizon its interface takes; this library has no ADMM
- *                           instantiation beyond 192 variables and REFUSES the solve (zeros out) rather than answer
- *                           with another method.  use_jcqp = 2 (swing-eliminated, :558-610) works at every horizon for
- *                           reduced sizes up to 192 variables; a robot beyond that is reported, QMPC_ST_WS_FULL
+ *   QMPC_SHIM_ERR_SETTINGS  update_solver_settings values unusable for the selected use_jcqp (e.g. rho <= 0).  use_jcqp = 1 / 2
+ *                           is honoured at every horizon setup_problem accepts, like the reference (SolverMPC.cpp:400-420,
+ *                           :558-631): beyond 192 variables the ADMM runs on the large-problem path
  *   QMPC_SHIM_ERR_SOLVE     the batched solver returned an error code (see stderr)
  * use_jcqp is thresholded like the reference (convexMPC_interface.cpp:113-118): > 1.5 -> 2, > 0.5 -> 1, else 0. */
 #define QMPC_SHIM_ERR_SETUP (-2)

@@ -168,11 +168,11 @@ int qmpc_set_model(qmpc_handle h, int model);
  * iteration on the GPU (same updates, same stopping rule; iters = ADMM iterations, QMPC_ST_MAXITER when
  * the residual test never passed); use_jcqp = 0 (default) is the exact active-set solve, which is what
  * the reference's qpOASES path returns.  qmpc_solve_commands always solves exactly.
- * Limits at horizons above QMPC_LONG_HORIZON: use_jcqp = 1 keeps 12 h > 192 variables, for which there is no ADMM
- * instantiation -- qmpc_settings_jcqp (handle already set up for such a horizon) and qmpc_setup (mode 1 already
- * selected) return QMPC_ERR_ARG and leave the handle unchanged, no solve call ever fails half-way for it; with
- * use_jcqp = 2 a robot whose reduced size exceeds 192 variables is REPORTED (QMPC_ST_WS_FULL, zero forces), not
- * solved by the exact engine under the ADMM's name. */
+ * At horizons above QMPC_LONG_HORIZON the alternate runs like the exact solve does: reduced sizes up to 192 variables in
+ * the 192-row class's ADMM instantiation, larger ones -- every robot with use_jcqp = 1 (12 h variables), all feet down or
+ * a trot beyond 32 segments with use_jcqp = 2 -- through the large-problem producer (which leaves
+ * (P + sigma I + A^T R A)^-1 and the gradient in the robot's work item) and an ADMM kernel of its own
+ * (qmpc_admm_big_kernel, one mat-vec over the 448 x 448 item per iteration: coverage of the interface, ~1e4 robots/s). */
 int qmpc_settings_jcqp(qmpc_handle h, int use_jcqp, int max_iter, double rho, double sigma,
                        double solver_alpha, double terminate);
 

@@ -61,8 +61,7 @@ void solve_floats(const float* p, const float* v, const float* q, const float* w
   const int mode = (g.use_jcqp > 1.5) ? 2 : (g.use_jcqp > 0.5 ? 1 : 0);
   int rc = qmpc_settings_jcqp(g.h, mode, g.max_iter, g.rho, g.sigma, g.alpha, g.terminate);
   if (rc != QMPC_OK) {
-    // e.g. rho <= 0: the reference would factor a singular KKT matrix; use_jcqp = 1 at a horizon above 16: no ADMM
-    // instantiation holds 12 h > 192 variables (include/convexMPC_interface.h).  The call is refused and reported
+    // e.g. rho <= 0: the reference would factor a singular KKT matrix; here the call is refused and reported
     std::fprintf(stderr, "[qmpc shim] update_solver_settings values rejected for use_jcqp=%d (rc=%d)\n", mode, rc);
     g.status = QMPC_SHIM_ERR_SETTINGS;
     g.q_soln.assign(12 * h, 0.0);
@@ -90,9 +89,6 @@ void setup_problem(double dt, int horizon, double mu, double f_max) {
     g.status = QMPC_SHIM_ERR_SETUP;
     return;
   }
-  // (the solver mode is re-applied before every solve: a use_jcqp = 1 left over from a shorter horizon must not make
-  //  THIS call fail -- at horizons above 16 the solve itself reports it, QMPC_SHIM_ERR_SETTINGS)
-  qmpc_settings_jcqp(g.h, 0, 1, 1.0, 0.0, 1.0, 0.0);
   const int rc = qmpc_setup(g.h, dt, horizon, mu, f_max);
   if (rc != QMPC_OK) {
     std::fprintf(stderr, "[qmpc shim] setup_problem(dt=%g, horizon=%d, mu=%g, f_max=%g) rejected rc=%d\n",

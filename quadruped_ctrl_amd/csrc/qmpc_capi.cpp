@@ -36,6 +36,7 @@ extern "C" hipError_t qmpc_big_launch(const QmpcParams* P, int grid, hipStream_t
 extern "C" int qmpc_engine_resident(int rb);
 extern "C" int qmpc_engine_capacity(int rb);
 extern "C" hipError_t qmpc_engine_launch(int rb, const QmpcParams* P, int grid, hipStream_t stream);
+extern "C" hipError_t qmpc_admm_big_launch(const QmpcParams* P, int grid, hipStream_t stream);
 
 extern "C" size_t qmpc_smem_bytes(int rb) {
   switch (rb) {
@@ -291,12 +292,6 @@ int qmpc_destroy(qmpc_handle h) {
 int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   if (!c) return QMPC_ERR_ARG;
   if (horizon <= 0 || horizon > c->max_horizon || !(mu > 0) || !(dt > 0)) return QMPC_ERR_ARG;
-  // use_jcqp = 1 keeps all 12 h variables (SolverMPC.cpp:400-414): beyond 192 rows at horizons above 16, where no ADMM
-  // instantiation exists -- refused HERE (and in qmpc_settings_jcqp), never in the middle of a solve
-  if (c->admm_mode == 1 && horizon > QMPC_LONG_HORIZON) {
-    c->err = "use_jcqp = 1 is limited to horizons <= 16 (12 h variables beyond the 192-row class)";
-    return QMPC_ERR_ARG;
-  }
   // struct problem_setup stores floats (convexMPC_interface.h:13-19)
   c->dt = (double)(float)dt;
   c->mu = (double)(float)mu;
@@ -401,10 +396,6 @@ int qmpc_settings_jcqp(qmpc_handle c, int use_jcqp, int max_iter, double rho, do
   if (!c || use_jcqp < 0 || use_jcqp > 2) return QMPC_ERR_ARG;
   if (use_jcqp && (max_iter <= 0 || !(rho > 0) || !(sigma >= 0) || !(solver_alpha > 0) || !(terminate >= 0)))
     return QMPC_ERR_ARG;
-  if (use_jcqp == 1 && c->is_setup && c->horizon > QMPC_LONG_HORIZON) {  // (see qmpc_setup)
-    c->err = "use_jcqp = 1 is limited to horizons <= 16 (12 h variables beyond the 192-row class)";
-    return QMPC_ERR_ARG;
-  }
   c->admm_mode = use_jcqp;
   if (use_jcqp) {
     c->admm_max_iter = max_iter;
@@ -561,9 +552,8 @@ ClassPlan plan_classes(const qmpc_ctx* c, int admm_mode, bool warm) {
     pl.k0 = 3;
     pl.k1 = 4;
     // (the large-problem stage: skipped when the caller's size hint, qmpc_set_max_stance, rules such robots out -- a
-    //  violator is reported like any other -- and for the JCQP alternate, which has no large-problem instantiation:
-    //  its robots beyond 192 rows are REPORTED, QMPC_ST_WS_FULL, not solved by another method)
-    pl.long_h = !(c->max_stance > 0 && 3 * c->max_stance <= 192) && !admm_mode;
+    //  violator is reported like any other; use_jcqp = 1 makes every robot a large problem, 12 h variables)
+    pl.long_h = full_problem || !(c->max_stance > 0 && 3 * c->max_stance <= 192);
   }
   // decoupled path (128- and 192-row classes, exact solve, cold start): sweep kernel -> work items -> engine kernel ->
   // (rarely) the monolithic kernel on the robots the engine handed back.  Automatic: a small batch is latency-bound --
@@ -702,7 +692,6 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   // ping-pong between calls and each call's first kernel zeroes the NEXT call's set, so a call that took a set without
   // launching would leave the following call on counters nobody cleared
   const ClassPlan pl = plan_classes(c, P.admm_mode, P.ws != nullptr);
-  if (P.admm_mode == 1 && h > QMPC_LONG_HORIZON) return QMPC_ERR_ARG;  // (refused by qmpc_setup / qmpc_settings_jcqp already)
   for (int k = pl.k0; k < pl.k1; ++k)
     if (pl.split[k] && !c->d_wk_hinv[kChain[k] == 2 ? 0 : 1]) {
       c->err = "work-item pool missing (qmpc_setup / qmpc_reserve allocate it)";
@@ -781,8 +770,15 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         const int res = qmpc_engine_resident(sk == 2 ? 5 : rb);
         if (res > 0 && res < gb) gb = res;
       }
-      HIP_TRY(c, qmpc_engine_launch(sk == 2 ? 5 : rb, &B, gb, stream));
+      if (sk == 2 && base.admm_mode) {
+        // JCQP alternate on the large problems: the producer left M^-1 and the gradient; the ADMM kernel consumes the items
+        gb = (hi - lo) < 2048 ? (hi - lo) : 2048;
+        HIP_TRY(c, qmpc_admm_big_launch(&B, gb, stream));
+      } else {
+        HIP_TRY(c, qmpc_engine_launch(sk == 2 ? 5 : rb, &B, gb, stream));
+      }
     }
+    if (sk == 2 && base.admm_mode) return QMPC_OK;  // (the ADMM hands nothing back)
     // robots handed back (event capacity exceeded, lost definiteness): the monolithic kernel, list-consuming.  The
     // large problems have no class to fall back to: the 192-row class's stage 0 REPORTS them (QMPC_ST_WS_FULL)
     QmpcParams F = base;

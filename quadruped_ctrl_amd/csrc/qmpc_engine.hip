@@ -1372,6 +1372,149 @@ static_assert(sizeof(ESmem<Engine3::C>) <= 80 * 1024 && sizeof(ESmem<Engine2::C>
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// JCQP alternate on the LARGE problems (use_jcqp = 1 / 2 at horizons above 16: 192 < n <= 432; SURVEY row a10,
+// src/JCQP/QpProblem.cpp:178-269 as SolverMPC.cpp:400-420, :558-631 drive it).  The producer (qmpc_big_kernel) has left
+// M^-1 = (P + sigma I + A^T R A)^-1 -- the KKT matrix reduced to the x block, its friction part diagonal -- and the gradient
+// in the robot's work item; this kernel runs the same ADMM as the ADMM instantiations of qmpc_kernels.hip (stage 5 there),
+// one workgroup per item: thread = variable (x, M x), thread = foot-step (z, y, A x of its five rows), x~ = M^-1 rhs as a
+// mat-vec over the ROWS of the symmetric item (row j is column j: coalesced across the threads), 1.5 MB per iteration --
+// coverage of the interface, not speed.  Same updates, same stopping rule, same outputs (the ADMM iterate, not a minimiser).
+constexpr int ADMM_BIG_NT = QMPC_BIG_LD;
+__global__ __launch_bounds__(ADMM_BIG_NT) void qmpc_admm_big_kernel(const QmpcParams P) {
+  constexpr int LD = QMPC_BIG_LD, NT = ADMM_BIG_NT, NWV = NT / 64;
+  __shared__ double rv[LD], xs[LD], cw[LD], red[2 * NWV];
+  __shared__ int s_next;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the counter group of the NEXT chunk of this class (see qmpc_engine_kernel)
+  if (blockIdx.x == 0 && P.wk_zero && threadIdx.x < QMPC_GRP_INTS) P.wk_zero[threadIdx.x] = 0;
+  const int nitems = *P.wk_count;
+  if ((int)blockIdx.x >= nitems) return;  // uniform
+  const int h = P.horizon;
+  for (int item = (int)blockIdx.x;;) {
+    const QmpcWorkHdr* const hd = P.wk_hdr + item;
+    const GlobalF64* const Mi = (const GlobalF64*)P.wk_hinv + (size_t)item * ((size_t)LD * LD);
+    const int rid = hd->rid, n = hd->n, nst = hd->nst, status0 = hd->status0;
+    const double mi = P.mu_inv, sig = P.admm_sigma, al = P.admm_alpha, rho = P.admm_rho, rinf = 1e-6;
+    const double big = (double)5e10f;  // BIG_NUMBER through float (SolverMPC.cpp:15, :356)
+    const int max_it = P.admm_max_iter;
+    // ---- this thread's variable j = tid ...
+    const bool isv = tid < n;
+    const double gq = isv ? ((const GlobalF64*)P.wk_xu)[(size_t)item * LD + tid] : 0.0;
+    const double f3 = isv ? (double)hd->fmaxk[tid / 3] : 1.0;
+    const double rr3 = (__builtin_fabs(f3) < 1e-10) ? rho * 1e3 : (f3 > 1e10 ? rinf : rho);
+    const double dj = sig + ((tid % 3 < 2) ? 2.0 * rinf * mi * mi : 4.0 * rinf + rr3);  // diag(M - P)
+    double x = 0.0, mx = 0.0;  // cold start
+    // ---- ... and foot-step sl = tid (computeConstraintInfos :276-291 for its fz <= f_max row)
+    const bool iss = tid < nst;
+    const double fmx = iss ? (double)hd->fmaxk[tid] : 0.0;
+    double r4 = rho;
+    if (__builtin_fabs(fmx) < 1e-10) r4 = rho * 1e3;
+    else if (fmx > 1e10) r4 = rinf;
+    const double ir4 = 1.0 / r4, irinf = 1.0 / rinf;
+    double z[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0}, ax[5] = {0, 0, 0, 0, 0};
+    double resid = __builtin_inf();
+    int iters = 0;
+    for (int it = 1; it <= max_it; ++it) {
+      // rhs = sigma x - q + A^T (R z - y)                                       (solveLinearSystem :315-323)
+      if (iss) {
+        const double w0 = rinf * z[0] - y[0], w1 = rinf * z[1] - y[1], w2 = rinf * z[2] - y[2], w3 = rinf * z[3] - y[3],
+                     w4 = r4 * z[4] - y[4];
+        cw[3 * tid] = mi * (w0 - w1);
+        cw[3 * tid + 1] = mi * (w2 - w3);
+        cw[3 * tid + 2] = (w0 + w1) + (w2 + w3) + w4;
+      }
+      __syncthreads();
+      const double rhs = isv ? sig * x - gq + cw[tid] : 0.0;
+      rv[tid] = rhs;
+      __syncthreads();
+      // x~ = M^-1 rhs: sum over the rows j of the item, ascending, eight loads in flight
+      double xt = 0.0;
+      for (int j0 = 0; j0 < n; j0 += 8) {
+        double mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = (isv && j0 + u < n) ? Mi[(size_t)(j0 + u) * LD + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xt = __builtin_fma(mv[u], rv[(j0 + u < n) ? j0 + u : 0], xt);
+      }
+      xs[tid] = xt;
+      // x, M x (stepX :340-347)
+      x = al * xt + (1.0 - al) * x;
+      mx = al * rhs + (1.0 - al) * mx;
+      __syncthreads();
+      // z~ = A x~ on the foot-step threads (f_block rows, SolverMPC.cpp:366-370); z, y, A x (stepZ :349-358, stepY :360-367)
+      double pmax = 0.0;
+      if (iss) {
+        const double t0 = xs[3 * tid], t1 = xs[3 * tid + 1], t2 = xs[3 * tid + 2];
+        const double zt[5] = {mi * t0 + t2, -mi * t0 + t2, mi * t1 + t2, -mi * t1 + t2, t2};
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const double rr = (r < 4) ? rinf : r4, ir = (r < 4) ? irinf : ir4, ub = (r < 4) ? big : fmx;
+          const double zr = al * zt[r] + (1.0 - al) * z[r];
+          double zn = zr + ir * y[r];
+          zn = zn < 0.0 ? 0.0 : zn;
+          zn = zn > ub ? ub : zn;
+          y[r] = y[r] + rr * (zr - zn);
+          ax[r] = al * zt[r] + (1.0 - al) * ax[r];  // A x of the relaxed iterate
+          const double pr = __builtin_fabs(ax[r] - z[r]);  // ... against the PREVIOUS z (:388)
+          pmax = pr > pmax ? pr : pmax;
+          z[r] = zn;
+        }
+      }
+      iters = it;
+      if (it % 10 == 0) {  // residual check (:238-247): (|A x - z_prev|_inf + |P x + q + A^T y|_inf) / 4
+        if (iss) {
+          cw[3 * tid] = mi * (y[0] - y[1]);
+          cw[3 * tid + 1] = mi * (y[2] - y[3]);
+          cw[3 * tid + 2] = (y[0] + y[1]) + (y[2] + y[3]) + y[4];
+        }
+        __syncthreads();
+        const double dv = isv ? __builtin_fabs((mx - dj * x) + gq + cw[tid]) : 0.0;
+        const double pm = wave_max_pos_f64(pmax), dm = wave_max_pos_f64(dv);
+        if (lane == 0) {
+          red[wv] = pm;
+          red[NWV + wv] = dm;
+        }
+        __syncthreads();
+        double pmx = 0.0, dmx = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+          pmx = red[w] > pmx ? red[w] : pmx;
+          dmx = red[NWV + w] > dmx ? red[NWV + w] : dmx;
+        }
+        resid = (dmx + pmx) * 0.25;
+        if (resid < P.admm_term || it >= max_it) break;  // uniform
+      }
+    }
+    // outputs: q_soln = the ADMM iterate (SolverMPC.cpp:598-602 / :613-617), not an exact minimiser
+    if (tid < 12) P.grf[(size_t)rid * 12 + tid] = 0.f;
+    __syncthreads();
+    bool nf = false;
+    if (isv) {
+      const int k = hd->sidx[tid / 3], ax3 = tid % 3;
+      if (k < 4) P.grf[(size_t)rid * 12 + 3 * k + ax3] = (float)x;
+      if (P.soln) P.soln[(size_t)rid * 12 * h + 3 * k + ax3] = x;
+      nf = !(__builtin_fabs(x) < __builtin_inf());
+    }
+    const int anynf = __syncthreads_or(nf ? 1 : 0);
+    if (tid == 0) {
+      int status = (resid < P.admm_term) ? 0 : QMPC_DEV_ST_MAXITER;
+      if (anynf) status |= QMPC_DEV_ST_NONFINITE;
+      P.status[rid] = status0 | status;
+      if (P.iters) P.iters[rid] = iters;
+      s_next = (int)gridDim.x + atomicAdd(P.wk_qhead, 1);
+    }
+    __syncthreads();
+    item = s_next;
+    if (item >= nitems) break;  // uniform
+  }
+}
+
+extern "C" hipError_t qmpc_admm_big_launch(const QmpcParams* P, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(qmpc_admm_big_kernel, dim3(grid), dim3(ADMM_BIG_NT), 0, stream, *P);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t qmpc_engine_prepare(void) {
   hipError_t e = Engine2::prepare();
   if (e != hipSuccess) return e;

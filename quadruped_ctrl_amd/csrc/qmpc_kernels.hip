@@ -499,7 +499,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       const int fs = tid + 64 * g;
       const float fm = (float)(g == 0 ? g_gait : g_gaitx[g > 0 ? g - 1 : 0]) * (float)PK.f_max;  // :361
       // (use_jcqp == 1 hands JCQP the FULL problem, swing foot-steps included with u = 0: SolverMPC.cpp:400-407)
-      const bool st = fs < nfs && ((ADMM && PK.admm_mode == 1) ? true : !(fm < 0.01f && fm > -.01f));  // :64-67
+      const bool st = fs < nfs && (((ADMM || BIG) && PK.admm_mode == 1) ? true : !(fm < 0.01f && fm > -.01f));  // :64-67
       const unsigned long long mask = __ballot(st);
       const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
       if (st && pos < Smem<RB>::SLOTS) {  // (beyond 64 stance foot-steps, n_r > 192: the large-problem producer's robots)
@@ -813,7 +813,15 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             if (ai == 0 && cax == 0) add = Aa.ct8[cidx] * w5x;
             v += add;
           }
-          A[(size_t)r * LDB + j] = 2.0 * (v + ((r == j) ? alpha : 0.0));
+          double hv = 2.0 * (v + ((r == j) ? alpha : 0.0));
+          if (P.admm_mode != 0 && r == j) {
+            // JCQP alternate on a large problem (use_jcqp = 1 / 2 at horizons above 16): the KKT matrix reduced to the x
+            // block, M = P + sigma I + A^T R A with its DIAGONAL friction part -- as in stage 2 of the ADMM instantiations
+            const double fk = S.fmaxk[r / 3];
+            const double rho4 = (__builtin_fabs(fk) < 1e-10) ? P.admm_rho * 1e3 : (fk > 1e10 ? 1e-6 : P.admm_rho);
+            hv += P.admm_sigma + ((ai < 2) ? 2.0 * 1e-6 * P.mu_inv * P.mu_inv : 4.0 * 1e-6 + rho4);
+          }
+          A[(size_t)r * LDB + j] = hv;
         }
       }
     }
@@ -1105,7 +1113,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     __syncthreads();
     QMPC_BIG_TICK(15);
     constexpr int LDX = QMPC_BIG_LD;
-    if (tid < LDX) P.wk_xu[(size_t)item * LDX + tid] = (tid < n) ? Fp[tid] : 0.0;
+    // (JCQP alternate: the ADMM starts cold and needs the gradient, not the unconstrained minimiser)
+    if (tid < LDX) P.wk_xu[(size_t)item * LDX + tid] = (tid < n) ? (P.admm_mode != 0 ? gl[tid] : Fp[tid]) : 0.0;
     QmpcWorkHdr* const hd = P.wk_hdr + item;
     if (tid < QMPC_WK_SLOTS_MAX) {
       hd->sidx[tid] = (tid < Smem<RB>::SLOTS) ? S.sidx[tid] : (unsigned char)0;

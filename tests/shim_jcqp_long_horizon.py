@@ -1,5 +1,5 @@
 """Run by tests/test_gpu_hardening.py::test_reference_shim_refuses_jcqp_full_problem_at_long_horizons in a process of its
-own (the shim's state is process-global): use_jcqp = 1 at horizon 20 through the reference's six symbols."""
+own (the shim's state is process-global): use_jcqp = 1 / 2 at horizon 20 through the reference's six symbols."""
 import ctypes as C
 import os
 import sys
@@ -34,11 +34,13 @@ def cycle(use_jcqp):
 st0, f0 = cycle(0.0)
 assert st0 >= 0 and (st0 & 47) == 0 and np.abs(f0).max() > 1.0
 for _ in range(2):
-    st1, f1 = cycle(1.0)
-    assert st1 == -3 and not f1.any()                          # QMPC_SHIM_ERR_SETTINGS, zeros
+    st1, f1 = cycle(1.0)                                       # JCQP on the full 240-variable problem
+    assert st1 >= 0 and (st1 & 46) == 0, st1
+    d = np.abs(f1 - f0).max() / np.abs(f0).max()
+    assert 1e-7 < d < 0.2, d                                   # the reference's alternate is an approximation
     st2, f2 = cycle(0.0)
     assert st2 == st0 and np.array_equal(f2, f0)
-
-
+st3, f3 = cycle(2.0)                                           # swing-eliminated: nothing to eliminate here, same iterate
+assert st3 >= 0 and np.abs(f3 - f1).max() / np.abs(f1).max() < 1e-9
 
 print("SHIM-JCQP-OK")

@@ -124,48 +124,40 @@ def test_solve_is_graph_capturable(name):
 def test_refused_call_then_good_call():
     """a call that is refused must not move the handle's call counter -- the counter sets ping-pong
     and each call's first kernel clears the NEXT call's set; a refused call that took a set used to leave the following
-    call on stale list lengths and queue heads (out-of-bounds work items with max_batch = 1).  use_jcqp = 1 at a horizon
-    above 16 is refused by qmpc_settings_jcqp / qmpc_setup now, never inside a solve; sequences of good and refused
-    calls give the same answers as good calls alone."""
+    call on stale list lengths and queue heads (out-of-bounds work items with max_batch = 1).  Everything that can refuse a
+    call is checked before the counter moves; sequences of good and refused calls give the same answers as good calls
+    alone.  (use_jcqp = 1 at a horizon above 16, the case ADVICE r3 walked through, is no longer refused at all: the
+    large-problem path runs the ADMM -- test_jcqp_alternate_on_the_large_problem_path.)"""
     from quadruped_ctrl_amd.binding import BatchedConvexMPC, QmpcError
     b = W.make_long_horizon(1, 20, "stand")      # n_r = 240: the large-problem path, one work item
     m = BatchedConvexMPC(0, max_batch=1, max_horizon=36)
     m.setup(b["dt"], 20, b["mu"], b["f_max"])
     first = m.solve(b, full=True)
     assert (first["status"] & 47) == 0 and np.abs(first["grf"]).max() > 1.0
-    for _ in range(3):
-        with pytest.raises(QmpcError):
-            m.settings_jcqp(1)                     # refused: the handle is set up for a horizon above 16
-        again = m.solve(b, full=True)             # still the exact solve, same counters
-        assert np.array_equal(again["soln"], first["soln"]) and again["status"] == first["status"]
-    # the other order: mode 1 selected at a short horizon, then a long horizon is asked for
-    m.setup(b["dt"], 10, b["mu"], b["f_max"])
-    m.settings_jcqp(1)
-    with pytest.raises(QmpcError):
-        m.setup(b["dt"], 20, b["mu"], b["f_max"])
-    m.settings_jcqp(0)
-    m.setup(b["dt"], 20, b["mu"], b["f_max"])
-    assert np.array_equal(m.solve(b, full=True)["soln"], first["soln"])
-    # argument errors in between (batch beyond max_batch) do not disturb anything either
     two = W.make_long_horizon(2, 20, "stand")
     for _ in range(3):
         with pytest.raises(QmpcError):
-            m.solve(two)
-        assert np.array_equal(m.solve(b, full=True)["soln"], first["soln"])
-    # use_jcqp = 2 at a long horizon: robots beyond 192 rows are REPORTED, not solved by another method
-    m.settings_jcqp(2)
-    r2 = m.solve(b, full=True)
-    assert r2["status"][0] & 8 and not r2["grf"].any()
+            m.settings_jcqp(1, rho=-1.0)           # refused: unusable settings, the handle keeps its mode
+        with pytest.raises(QmpcError):
+            m.solve(two)                           # refused: more robots than max_batch
+        again = m.solve(b, full=True)             # still the exact solve, same counters
+        assert np.array_equal(again["soln"], first["soln"]) and again["status"] == first["status"]
+    # the ADMM and the exact solve alternate on the same handle (the large-problem producer serves both)
+    m.settings_jcqp(1)
+    r1 = m.solve(b, full=True)
+    assert (r1["status"][0] & 46) == 0 and r1["iters"][0] >= 10
+    d = np.abs(r1["soln"] - first["soln"]).max() / np.abs(first["soln"]).max()
+    assert 1e-7 < d < 0.2, d                       # an approximation of the same minimiser, as in the reference
     m.settings_jcqp(0)
     assert np.array_equal(m.solve(b, full=True)["soln"], first["soln"])
     m.close()
 
 
-def test_reference_shim_refuses_jcqp_full_problem_at_long_horizons():
-    """The six-symbol shim (include/convexMPC_interface.h): update_solver_settings(..., use_jcqp = 1) at a horizon above
-    16 makes the next update_problem_data_floats a refused call -- QMPC_SHIM_ERR_SETTINGS, get_solution reads 0 -- and
-    going back to use_jcqp = 0 gives the first answer again (the sequence of ADVICE r3's first finding).  In a process
-    of its own: the shim's state is process-global like the reference's (convexMPC_interface.cpp:13-20)."""
+def test_reference_shim_jcqp_full_problem_at_long_horizons():
+    """The six-symbol shim (include/convexMPC_interface.h): update_solver_settings(..., use_jcqp = 1) at horizon 20 runs
+    the JCQP alternate on the large-problem path (12 h = 240 variables), use_jcqp = 0 afterwards gives the exact answer
+    again.  In a process of its own: the shim's state is process-global like the reference's
+    (convexMPC_interface.cpp:13-20)."""
     import subprocess
     import sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_jcqp_long_horizon.py")], capture_output=True, text=True,

@@ -580,6 +580,56 @@ def test_jcqp_alternate_vs_model(mpc_factory):
             assert np.array_equal(m.solve(b, full=True)["soln"], exact)      # back to the exact solve
 
 
+@pytest.mark.parametrize("h,gait,mode", [(20, "stand", 1), (20, "stand", 2), (24, "trot", 1), (36, "trot", 2), (36, "stand", 1)])
+def test_jcqp_alternate_on_the_large_problem_path(h, gait, mode, mpc_factory):
+    """use_jcqp = 1 / 2 at horizons above 16 (VERDICT r3 missing 3: the reference runs its alternate at any horizon its
+    interface takes, SolverMPC.cpp:406-420).  Problems beyond 192 variables -- every robot with use_jcqp = 1 (12 h
+    variables), all feet down / trot at 36 segments with use_jcqp = 2 -- go through the large-problem producer, which leaves
+    M^-1 = (P + sigma I + A^T R A)^-1 and the gradient in the work item, and qmpc_admm_big_kernel.  (a) end to end against
+    the numpy restatement of QpProblem::runFromDense on the float-assembled QP: iteration count within one residual check,
+    iterate within the float-assembly noise the settings amplify; (b) the ADMM arithmetic: the restatement fed the GPU's
+    OWN M (the work item's inverse, inverted back) and gradient -> same iteration count, iterate <= 1e-6."""
+    from oracle import jcqp_model as J
+    B = 4
+    b = W.make_long_horizon(B, h, gait)
+    m = mpc_factory(b)
+    exact = m.solve(b, full=True)["soln"]
+    m.settings_jcqp(mode)
+    res = m.solve(b, full=True)
+    assert ((res["status"] & 46) == 0).all(), res["status"]
+    rho, sigma = 1e-7, 1e-8
+    items = {}
+    for it in range(B):
+        hinv, xu, hdr = m.debug_read_item(2, it)
+        items[int(hdr[0])] = (hinv, xu, int(hdr[1]))
+    nbig = 0
+    for i in range(B):
+        P_, q_, A_, l_, u_, vi = J.mpc_problem(b, i, mode)
+        n = q_.size
+        if n <= 192:
+            continue
+        nbig += 1
+        x, itn, resid = J.solve(b, i, mode)
+        assert abs(int(res["iters"][i]) - itn) <= 10, (i, res["iters"][i], itn)
+        # (the float assembly's own evaluation-order spread is 1e-3 .. 1e-2 at these horizons, oracle/noise_floor.py, and
+        #  rho = 1e-7 amplifies it)
+        assert np.abs(res["soln"][i] - x).max() / max(np.abs(x).max(), 1.0) < (2e-3 if h < 30 else 1e-2)
+        hinv, g, nn = items[i]
+        assert nn == n
+        R = J.constraint_rho(l_, u_, rho)
+        extra = sigma + (A_ * A_ * R[:, None]).sum(0)
+        Pg = np.linalg.inv(hinv[:n, :n]) - np.diag(extra)
+        Pg = 0.5 * (Pg + Pg.T)
+        xg, itg, rg = J.run_from_dense(Pg, g[:n], A_, l_, u_, 10000, rho, sigma, 1.5, 0.1)
+        assert res["iters"][i] == itg, (i, res["iters"][i], itg)
+        assert np.abs(res["soln"][i][vi] - xg).max() / max(np.abs(xg).max(), 1.0) < 1e-6
+    assert nbig >= (B if mode == 1 else 1)
+    d = np.abs(res["soln"] - exact).max() / np.abs(exact).max()
+    assert 1e-7 < d < 0.2, d
+    m.settings_jcqp(0)
+    assert np.array_equal(m.solve(b, full=True)["soln"], exact)
+
+
 def test_reference_shim_at_the_interface_maximum_of_36_segments():
     """setup_problem(horizon = K_MAX_GAIT_SEGMENTS) through the reference's six functions, for a trot (n_r = 216) and with
     all four feet down (n_r = 432): the large-problem path behind the shim.  Bit for bit the batched C ABI's result (same
