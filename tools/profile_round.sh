@@ -35,12 +35,15 @@ python $R/bench.py --steps 20 --warmup 3 --workload long-stand --horizon 36 --no
 for w in "large_trot_h36 long-trot 36 30" "large_stand_h36 long-stand 36 20"; do
   set -- $w
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$1 -o s --output-format csv -- \
-      python $R/bench.py --steps $4 --warmup 3 --workload $2 --horizon $3 --no-cpu-baseline --no-pipelined > $OUT/stats_$1.log 2>&1
+      python $R/bench.py --steps $4 --warmup 3 --repeats 3 --workload $2 --horizon $3 --no-cpu-baseline --no-pipelined > $OUT/stats_$1.log 2>&1
   find $OUT/stats_$1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$1.csv \;
   rm -rf $OUT/stats_$1
+  # (round 4: counters for the large-problem producer as well -- FETCH_SIZE / WRITE_SIZE behind the "memory-system limit" of DESIGN 3.6)
+  bash $R/tools/pmc.sh $TAG/pmc_$1 --no-pipelined --workload $2 --horizon $3 --steps 5 --warmup 1 > $OUT/pmc_$1.log 2>&1
+  cp $OUT/pmc_$1/pmc_summary.json $OUT/pmc_summary_$1.json 2>/dev/null
+  rm -rf $OUT/pmc_$1/p[0-9]*
 done
-python $R/tools/stress_large.py 160 2>/dev/null | grep -v amdgpu > $OUT/stress_parity_large.txt
-QMPC_STRESS_SPLIT=1 python $R/tools/stress_parity.py 400 2>/dev/null | grep -v amdgpu > $OUT/stress_parity_decoupled.txt
+python $R/tools/jcqp_long.py 2>/dev/null | grep -v amdgpu > $OUT/jcqp_long.txt
 # the same standing workloads on the one-kernel path (before / after of the decoupled path in ONE profile set)
 for hh in 10 14 16; do
   QMPC_NO_SPLIT=1 python $R/bench.py --steps 200 --workload standing --horizon $hh --no-cpu-baseline --no-pipelined > $OUT/bench_standing_h${hh}_one_kernel.json 2>/dev/null
@@ -51,9 +54,9 @@ python $R/tools/engine_phase.py s14 1024 2>/dev/null | grep -v amdgpu >> $OUT/en
 # (the sweep kernels' stage stamps: robots the engine kernel did not stamp over)
 QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s10 1024 2>/dev/null | grep -v amdgpu | head -7 > $OUT/sweep_phases.txt
 QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s14 1024 2>/dev/null | grep -v amdgpu | head -7 >> $OUT/sweep_phases.txt
-python $R/tools/chunk_sweep.py 2>/dev/null | grep -v amdgpu > $OUT/chunk_sweep.txt
 # bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
 for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
+for v in 3 256 512; do python $R/tools/sweep_step_phase.py 3 $v 2>/dev/null | grep -v amdgpu; done > $OUT/sweep_step_phase_note.txt
 for a in "--config 4 --batch 8192" "--workload standing --horizon 10 --batch 1024" "--workload standing --horizon 16 --batch 1024"; do python $R/tools/class_stats.py $a; done > $OUT/class_stats.txt 2>/dev/null
 for b in 256 4096 16384 65536; do python $R/bench.py --steps 100 --batch $b --no-cpu-baseline --no-pipelined > $OUT/bench_cfg1_b$b.json 2>/dev/null; done
 python $R/bench.py --steps 100 --caller-side fused --no-cpu-baseline > $OUT/bench_caller_fused.json 2>/dev/null
