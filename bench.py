@@ -519,6 +519,10 @@ def main():
                                  "never executes. " + pmc_note}, **pmc_extra),
             "roofline_hbm": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                             # what the memory system really moved (PMC bytes per step over the HIP-event time): the large-problem
+                             # producer streams its 1.5 MB work items through HBM once per block step and IS bound here
+                             "traffic_rate_gbs": (traffic / t_s / 1e9 if traffic else None),
+                             "traffic_frac_of_peak": (traffic / t_s / 1e9 / HBM_PEAK_GBS if traffic else None),
                              "alg_bytes_per_qp": alg_bytes_per_qp(h),
                              "note": "728 B in + 48 B out per robot at h=10: tiny by construction"},
         }

@@ -10,7 +10,7 @@ qmpc_solve), the work is enqueued on torch's CURRENT stream, nothing synchronise
 the hand-written HIP kernels of libqmpc.so.  There is no CPU implementation: the op is registered for
 the "cuda" device type only, so a CPU tensor fails loudly in the dispatcher.
 
-Handles are cached per (device, horizon, dt) -- what the handle's tables depend on; mu and f_max are
+Handles are cached per (device, horizon, dt, max_stance_hint) -- what the handle's tables and pools depend on; mu and f_max are
 plain parameters of the next launch, so sweeping them (domain randomisation) reuses ONE handle -- and
 grown when a larger batch arrives.  The cache holds at most MAX_HANDLES entries (least recently used
 is destroyed: a handle owns a few hundred MB of event pools).  One handle serialises its calls
@@ -25,16 +25,23 @@ from . import binding as _b
 
 _handles = OrderedDict()
 MAX_HANDLES = 4
+# Caller's bound on stance foot-steps per robot (qmpc_set_max_stance; 0 = unknown), applied to handles created from now
+# on BEFORE their setup: qmpc_setup allocates the pools of every size class the bound leaves reachable -- at horizons
+# above 16 an unhinted 1024-robot handle owns 1.5 GiB of large-problem work items that a trot (2 feet x h <= 64
+# foot-steps) never uses.  A robot beyond the bound is reported (QMPC_ST_WS_FULL), not solved.
+max_stance_hint = 0
 
 
 def _solver(device, horizon, dt, mu, f_max, batch):
-    key = (device.index, int(horizon), float(dt))
+    key = (device.index, int(horizon), float(dt), int(max_stance_hint))
     ent = _handles.get(key)
     if ent is None or ent[1] < batch:
         if ent is not None:
             ent[0].close()
         cap = max(int(batch), 1024)
         m = _b.BatchedConvexMPC(device.index, max_batch=cap, max_horizon=_b_max_horizon())
+        if max_stance_hint:
+            m.set_max_stance(int(max_stance_hint))
         ent = (m, cap)
         _handles[key] = ent
         while len(_handles) > MAX_HANDLES:            # least recently used first

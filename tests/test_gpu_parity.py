@@ -1512,6 +1512,19 @@ def test_torch_custom_op(mpc_factory):
     torch.library.opcheck(torch.ops.qmpc.solve, (*args, b["dt"], b["mu"], b["f_max"], True),
                           test_utils=("test_schema", "test_faketensor"))
     T.release_handles()
+    # a long horizon with the stance hint: the handle does not take the large-problem pool (1.5 GiB at 1024 robots)
+    lt = W.make_long_horizon(64, 24, "trot")
+    free0 = torch.cuda.mem_get_info()[0]
+    T.max_stance_hint = 48
+    tl = [torch.from_numpy(np.ascontiguousarray(lt[k])).to(dev) for k in
+          ("p", "v", "q", "w", "r", "yaw", "traj", "gait", "weights", "alpha", "x_drag")]
+    gl = torch.ops.qmpc.solve(*tl, lt["dt"], lt["mu"], lt["f_max"], False)[0]
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 1.2 * 2**30
+    # (the operator's 1024-robot handle takes the decoupled path, a 64-robot handle the one-kernel path: same minimiser)
+    assert np.abs(gl.cpu().numpy() - mpc_factory(lt).solve(lt)["grf"]).max() < 1e-4
+    T.max_stance_hint = 0
+    T.release_handles()
 
 
 @pytest.mark.parametrize("gait,h", [("trot", 10), ("mixed", 10), ("stand", 10), ("trot", 16)])

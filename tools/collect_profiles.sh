@@ -12,8 +12,8 @@ done
 cp gpurun_out/$T/shim_latency.json profiles/${T}_shim_latency.json
 cp gpurun_out/$T/warm_rollout.json profiles/${T}_warm_rollout.json
 cp gpurun_out/$T/class_stats.txt profiles/${T}_class_stats.txt 2>/dev/null || true
-for f in large_trot_h36 large_stand_h36; do cp gpurun_out/$T/kernel_stats_$f.csv profiles/${T}_kernel_stats_$f.csv 2>/dev/null || true; done
-for f in split_check engine_phases sweep_phases chunk_sweep stress_parity_large stress_parity_decoupled; do cp gpurun_out/$T/$f.txt profiles/${T}_$f.txt 2>/dev/null || true; done
+for f in large_trot_h36 large_stand_h36; do cp gpurun_out/$T/kernel_stats_$f.csv profiles/${T}_kernel_stats_$f.csv 2>/dev/null || true; cp gpurun_out/$T/pmc_summary_$f.json profiles/${T}_pmc_summary_$f.json 2>/dev/null || true; done
+for f in split_check engine_phases sweep_phases jcqp_long; do cp gpurun_out/$T/$f.txt profiles/${T}_$f.txt 2>/dev/null || true; done
 for f in long_trot_h24 long_bound_h36 large_trot_h36 large_standing_h24 large_stand_h36 standing_h10_one_kernel standing_h14_one_kernel standing_h16_one_kernel; do
   cp gpurun_out/$T/bench_$f.json profiles/${T}_bench_$f.json 2>/dev/null || true
 done
@@ -44,6 +44,10 @@ rm -f profiles/pmc_latest.json
 for pair in "cfg1 config1 1024" "standing_h10 standing_h10 1024" "standing_h14 standing_h14 1024" "standing_h16 standing_h16 1024" "trot_h16 config3 4096"; do
   set -- $pair
   python tools/pmc_to_latest.py profiles/${T}_pmc_summary_$1.json $2 $3 profiles/${T}_pmc_summary_$1.json profiles/${T}_kernel_stats_$1.csv > /dev/null
+done
+for pair in "large_stand_h36 long-stand_h36 1024" "large_trot_h36 long-trot_h36 1024"; do
+  set -- $pair
+  [ -f profiles/${T}_pmc_summary_$1.json ] && python tools/pmc_to_latest.py profiles/${T}_pmc_summary_$1.json $2 $3 profiles/${T}_pmc_summary_$1.json profiles/${T}_kernel_stats_$1.csv > /dev/null
 done
 python -c "
 import json; d=json.load(open('profiles/pmc_latest.json')); [print(k, int(v['hbm_bytes_per_launch']), '%.3g'%v['fp64_flops_per_launch'], v['kernel_source_sha'], {a:round(b,2) for a,b in v['wave_cycle_shares'].items()}) for k,v in d.items()]"

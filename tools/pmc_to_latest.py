@@ -20,9 +20,9 @@ summ = json.load(open(src if os.path.isfile(src) else os.path.join(src, "pmc_sum
 # every solve-path kernel of a step (one-kernel classes: qmpc_solve_kernel; decoupled classes: qmpc_sweep_kernel +
 # qmpc_engine_kernel + the hand-back launch): counters are per dispatch, a step dispatches each of them once, so the
 # per-step figure is the sum weighted by dispatches / steps; `name` = the one with the most wave cycles
-ks = {k: v for k, v in summ.items() if "qmpc_" in k and ("solve_kernel" in k or "sweep_kernel" in k or "engine_kernel" in k or "admm_kernel" in k)}
-steps = max(v.get("dispatches", 1) for v in ks.values())
+ks = {k: v for k, v in summ.items() if "qmpc_" in k and ("solve_kernel" in k or "sweep_kernel" in k or "engine_kernel" in k or "admm_kernel" in k or "big_kernel" in k)}
 name = max(ks, key=lambda k: ks[k].get("SQ_WAVE_CYCLES", 0) * ks[k].get("dispatches", 1))
+steps = ks[name].get("dispatches", 1)   # (the dominant kernel runs once per step; a hand-back kernel may run twice)
 d = {}
 for k, v in ks.items():
     wgt = v.get("dispatches", steps) / steps

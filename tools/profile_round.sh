@@ -56,7 +56,6 @@ QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s10 1024 2>/dev/null | gre
 QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s14 1024 2>/dev/null | grep -v amdgpu | head -7 >> $OUT/sweep_phases.txt
 # bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
 for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
-for v in 3 256 512; do python $R/tools/sweep_step_phase.py 3 $v 2>/dev/null | grep -v amdgpu; done > $OUT/sweep_step_phase_note.txt
 for a in "--config 4 --batch 8192" "--workload standing --horizon 10 --batch 1024" "--workload standing --horizon 16 --batch 1024"; do python $R/tools/class_stats.py $a; done > $OUT/class_stats.txt 2>/dev/null
 for b in 256 4096 16384 65536; do python $R/bench.py --steps 100 --batch $b --no-cpu-baseline --no-pipelined > $OUT/bench_cfg1_b$b.json 2>/dev/null; done
 python $R/bench.py --steps 100 --caller-side fused --no-cpu-baseline > $OUT/bench_caller_fused.json 2>/dev/null

@@ -1,4 +1,4 @@
-R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r03_j_rebench; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/${1:-rebench}; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() { local name=$1; shift; python $R/bench.py --steps 300 "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
 run cfg1
 run standing_h10 --workload standing --horizon 10
