@@ -526,6 +526,20 @@ def main():
                              "alg_bytes_per_qp": alg_bytes_per_qp(h),
                              "note": "728 B in + 48 B out per robot at h=10: tiny by construction"},
         }
+        if nr_max > 192:
+            # the large-problem path (192 < n_r <= 432): its producer streams the robot's 1.5 MB work item through HBM once per
+            # block step -- THAT is the roof it runs against; the fp64 figures (vector instructions only:
+            # the rank-16 updates run on the matrix cores and are not in those counters) move to roofline_fp64_valu
+            res["roofline_fp64_valu"] = res["roofline"]
+            rate = (traffic / t_s / 1e9) if traffic else ach
+            res["roofline"] = {"bound": "hbm", "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
+                               "frac_is": ("measured HBM traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE per step) over the HIP-event time" if traffic
+                                           else "algorithmic bytes (no PMC counters for this kernel source)"),
+                               "traffic": traffic, "alg_bytes_per_step": abytes,
+                               "kernel": "qmpc_big_kernel<%s> (+ qmpc_engine_kernel<7, ...>)" % cm, "kernel_ms_hip_events": step_ms_ev,
+                               "pmc_measured_in_this_run": False if traffic else None, "pmc_profile": pmc_extra.get("pmc_profile"),
+                               "note": "traffic well above the algorithmic bytes is inherent to inverting a 432 x 432 matrix that fits no "
+                                       "on-chip memory: 27 block steps x the lower triangle read and written once. " + pmc_note}
         if rank_devices is not None:
             res["rccl_world_size"] = world if os.environ.get("QMPC_BENCH_BACKEND", "nccl") == "nccl" else None
             res["world_size"] = world

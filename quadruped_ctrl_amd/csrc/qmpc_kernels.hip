@@ -195,7 +195,13 @@ struct Cfg {
   // one (z~, g~) record of NP + KS doubles per working-set change; Schur-form
   // engine: packed S_W^-1 (front) and rows H^-1 c_w (back).  Sized so that
   // class 1 keeps 4 workgroups per CU and class 4 two
-  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176));
+#ifndef QMPC_C1_POOL
+#define QMPC_C1_POOL 2688
+#endif
+#ifndef QMPC_C1_WAVES
+#define QMPC_C1_WAVES 4
+#endif
+  static constexpr int POOL = (RB == 1) ? QMPC_C1_POOL : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176));
   static constexpr int NPOOL = POOL;
   static constexpr int KS = (RB == 1) ? 32 : (RB == 3 ? 128 : 64);  // event-form engine: working-set slot capacity (class 3: two per lane)
   static constexpr bool EVENT_ENGINE = true;
@@ -223,7 +229,7 @@ struct Cfg {
   // K_MAX_GAIT_SEGMENTS = 36 (convexMPC_interface.h:3).  The long ones (h > 16) are assembled by the 192-row class only:
   // its 768 threads cover the 12 h <= 432 tracking-error entries one per thread, and it alone has the LDS for h x h tables
   static constexpr int HMAX = (RB == 3) ? 36 : 16;
-  static constexpr int MIN_WAVES = (RB == 1 || RB == 4) ? 4 : (RB == 2 ? 2 : 3);  // per SIMD (launch bounds)
+  static constexpr int MIN_WAVES = (RB == 1) ? QMPC_C1_WAVES : (RB == 4 ? 4 : (RB == 2 ? 2 : 3));  // per SIMD (launch bounds)
   // ... of the producer half of the decoupled path (qmpc_sweep_kernel): without the packed inverse its LDS is the
   // assembly / sweep storage only, so the 128-row class fits two workgroups per CU if it stays within 128 VGPRs
 #ifndef QMPC_SWEEP_WAVES2
