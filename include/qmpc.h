@@ -214,6 +214,13 @@ int qmpc_set_split(qmpc_handle h, int mode);
  * measured on MI355X not faster than the iteration it replaces: ~3.1 k cycles per forced change against
  * ~4.9 k per iteration, and 20 % more changes.  `iters` counts every forced change like an iteration. */
 int qmpc_set_block_start(qmpc_handle h, int on);
+/* The 64-row size class has a second instantiation sized for FIVE workgroups per CU (96 VGPRs, a 16-event pool in LDS
+ * instead of 28): a launch of several rounds of workgroups is bound by instruction issue, and a fifth wave per SIMD fills
+ * the slots the other four leave (trot: +3.5 % at 2048 robots, +8 % at 4096, +14 % from 8192 on); a single round (1024 robots)
+ * is bound by its slowest robot and would lose 1 - 11 %.  mode 1 (default): used by handles created for at least 2048 robots when the 64-row class is the
+ * whole chain (qmpc_set_max_stance says every robot fits it) -- the handle's size decides, never a call's; mode 0: never;
+ * mode 2: whenever the chain is that class alone.  Same arithmetic: bit-identical results (tested). */
+int qmpc_set_dense(qmpc_handle h, int mode);
 /* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for
  * the 128-row class / 192-row class / large problems -- whatever max_batch is; a call with more robots than items runs the
  * class as consecutive chunks (producer kernel, engine kernel, producer kernel, ...) on the caller's stream, the pool reused

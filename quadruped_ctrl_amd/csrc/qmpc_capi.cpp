@@ -28,6 +28,7 @@ QMPC_DECLARE_CLASS(1)
 QMPC_DECLARE_CLASS(2)
 QMPC_DECLARE_CLASS(3)
 QMPC_DECLARE_CLASS(4)
+QMPC_DECLARE_CLASS(6)
 
 // the decoupled path's consumer (qmpc_engine.hip)
 extern "C" hipError_t qmpc_engine_prepare(void);
@@ -44,6 +45,7 @@ extern "C" size_t qmpc_smem_bytes(int rb) {
     case 2: return qmpc_c2_smem();
     case 3: return qmpc_c3_smem();
     case 4: return qmpc_c4_smem();
+    case 6: return qmpc_c6_smem();
   }
   return 0;
 }
@@ -53,6 +55,7 @@ extern "C" int qmpc_resident_blocks(int rb) {
     case 2: return qmpc_c2_resident();
     case 3: return qmpc_c3_resident();
     case 4: return qmpc_c4_resident();
+    case 6: return qmpc_c6_resident();
   }
   return 0;
 }
@@ -60,6 +63,7 @@ static hipError_t qmpc_prepare(void) {
   hipError_t e;
   if ((e = qmpc_c1_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c4_prepare()) != hipSuccess) return e;
+  if ((e = qmpc_c6_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c2_prepare()) != hipSuccess) return e;
   if ((e = qmpc_c3_prepare()) != hipSuccess) return e;
   if ((e = qmpc_big_prepare()) != hipSuccess) return e;
@@ -75,6 +79,7 @@ static hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t
     case 2: return qmpc_c2_launch(P, grid, stream);
     case 3: return qmpc_c3_launch(P, grid, stream);
     case 4: return qmpc_c4_launch(P, grid, stream);
+    case 6: return qmpc_c6_launch(P, grid, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -127,6 +132,7 @@ struct qmpc_ctx {
   int wk_cap[3] = {0, 0, 0};    // work items per class: a bounded pool, min(max_batch, QMPC_ITEMS_*) -- ensure_pools
   int* d_fb_lists = nullptr;   // [3][max_batch] robots the engine kernels hand back (128-row, 192-row, large problems)
   bool block = false;          // qmpc_set_block_start (experimental, off: measured no faster); QMPC_BLOCK=1 in the environment switches it on at creation
+  int dense = 1;               // qmpc_set_dense: the 64-row class at five workgroups per CU -- 0 never, 1 automatic (by the handle's size), 2 whenever the chain is that class alone
   int chunks = 0;              // qmpc_set_chunks (test hook): run the item classes in at least this many chunks (0 / 1: as few as the pools allow)
   int dbg_engine_events = 0;   // test hook: events the engine may hold per robot (0 = the compiled capacity)
   unsigned call_no = 0;
@@ -218,7 +224,7 @@ int ensure_pools(qmpc_ctx* c);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 15; }
+int qmpc_abi_version(void) { return 16; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -439,6 +445,12 @@ int qmpc_set_split(qmpc_handle c, int on) {
 int qmpc_set_block_start(qmpc_handle c, int on) {
   if (!c) return QMPC_ERR_ARG;
   c->block = on != 0;
+  return QMPC_OK;
+}
+
+int qmpc_set_dense(qmpc_handle c, int mode) {
+  if (!c || mode < 0 || mode > 2) return QMPC_ERR_ARG;
+  c->dense = mode;
   return QMPC_OK;
 }
 
@@ -829,7 +841,16 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
       const int res = qmpc_resident_blocks(kChain[k]);
       if (res > 0 && res < grid) grid = res;
     }
-    HIP_TRY(c, qmpc_launch(kChain[k], &P, grid, stream));
+    // the 64-row class alone in the chain (the stance hint says every robot fits it), on a handle made for large batches:
+    // its five-workgroups-per-CU instantiation (same arithmetic, bit-identical results: tests) -- a launch of several rounds
+    // is bound by instruction issue, and the fifth wave per SIMD fills what four leave (trot: +3.5 % at 2048 robots, +8 % at 4096, +14 % from
+    // 8192 on: 3.76e7 -> 4.30e7 QP/s at 16384; mixed gaits +3 / +7 / +11 %: tools/dense_threshold.py); one round of workgroups
+    // (batch 1024) is bound by its slowest robot and loses 1 - 11 % to the 96-VGPR code.  By the
+    // HANDLE's size, never the call's.  Not for chains with larger classes: their robots iterate long, and 16 events in LDS
+    // instead of 28 send a thousand of them to the overflow pool (configs[4]: -40 %)
+    int kcls = kChain[k];
+    if (kcls == 1 && pl.k1 - pl.k0 == 1 && !pl.long_h && (c->dense == 2 || (c->dense == 1 && c->max_batch >= 2048))) kcls = 6;
+    HIP_TRY(c, qmpc_launch(kcls, &P, grid, stream));
   }
   if (pl.long_h) {
     // ---- the large problems (192 < n_r <= 432: all feet down beyond 16 segments, a trot beyond 32): H in global memory,

@@ -180,14 +180,18 @@ __device__ __forceinline__ void fmac8_rowbcast(double (&a)[8], double c, double 
 // workgroup per CU.
 template <int RB>
 struct Cfg {
-  static constexpr int NP = (RB == 4) ? 96 : 64 * RB;
+  // (RB = 6: the 64-row class once more, sized for FIVE workgroups per CU -- 96 VGPRs, 32 KB of LDS with a 16-event pool --
+  //  for handles of 4096 robots or more whose every robot fits the class: a large batch is bound by instruction issue, and a
+  //  fifth wave per SIMD fills the slots the other four leave; qmpc_capi.cpp decides)
+  static constexpr bool C1 = (RB == 1 || RB == 6);
+  static constexpr int NP = (RB == 4) ? 96 : (RB == 6 ? 64 : 64 * RB);
   static constexpr int CW = NP / 4;
   static constexpr int NT = 4 * NP;
   static constexpr int RE = (NP + 63) / 64;  // 64-row blocks of an index-major engine vector
   // Schur-form engine (the fallback): working-set slots.  Every n_r <= 64 problem fits 64; in the largest
   // class the 160 KiB of LDS next to the packed inverse set the bound at run time (48 slots at
   // n_r = 192, all 96 at n_r <= 168)
-  static constexpr int KMAX = (RB == 1) ? 64 : 96;
+  static constexpr int KMAX = C1 ? 64 : 96;
   static constexpr int KW = (KMAX + 63) / 64;  // slots per engine lane
   static constexpr int NS = KMAX * (KMAX + 1) / 2;
   static constexpr int NH = NP * (NP + 1) / 2;
@@ -195,15 +199,9 @@ struct Cfg {
   // one (z~, g~) record of NP + KS doubles per working-set change; Schur-form
   // engine: packed S_W^-1 (front) and rows H^-1 c_w (back).  Sized so that
   // class 1 keeps 4 workgroups per CU and class 4 two
-#ifndef QMPC_C1_POOL
-#define QMPC_C1_POOL 2688
-#endif
-#ifndef QMPC_C1_WAVES
-#define QMPC_C1_WAVES 4
-#endif
-  static constexpr int POOL = (RB == 1) ? QMPC_C1_POOL : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176));
+  static constexpr int POOL = (RB == 1) ? 2688 : (RB == 6 ? 1536 : (RB == 2 ? 11400 : (RB == 4 ? 5120 : 1176)));
   static constexpr int NPOOL = POOL;
-  static constexpr int KS = (RB == 1) ? 32 : (RB == 3 ? 128 : 64);  // event-form engine: working-set slot capacity (class 3: two per lane)
+  static constexpr int KS = C1 ? 32 : (RB == 3 ? 128 : 64);  // event-form engine: working-set slot capacity (class 3: two per lane)
   static constexpr bool EVENT_ENGINE = true;
   // class 3 has no LDS left for events: its event pool lives in global memory (one slice per workgroup in
   // flight, L2-resident: 2.5 KB per event), the LDS pool only serves the helper waves' partial sums and the
@@ -214,7 +212,7 @@ struct Cfg {
   static constexpr int KEV_GLOBAL = (RB == 3) ? 160 : 96;
   // waves 1..NHELP take a share of the stored events whenever there are enough of them to be worth two barriers
   // (the larger classes: long active-set runs, and seven or eleven waves with nothing else to do)
-  static constexpr int NHELP = (RB == 1) ? 0 : 3;
+  static constexpr int NHELP = C1 ? 0 : 3;
   // event records with the lane's entries stored adjacently (16-byte loads): the classes whose robots hold many
   // events; the record size is the same (NP and KS are multiples of 64 there)
 #ifndef QMPC_PAIRED
@@ -229,7 +227,7 @@ struct Cfg {
   // K_MAX_GAIT_SEGMENTS = 36 (convexMPC_interface.h:3).  The long ones (h > 16) are assembled by the 192-row class only:
   // its 768 threads cover the 12 h <= 432 tracking-error entries one per thread, and it alone has the LDS for h x h tables
   static constexpr int HMAX = (RB == 3) ? 36 : 16;
-  static constexpr int MIN_WAVES = (RB == 1) ? QMPC_C1_WAVES : (RB == 4 ? 4 : (RB == 2 ? 2 : 3));  // per SIMD (launch bounds)
+  static constexpr int MIN_WAVES = (RB == 1 || RB == 4) ? 4 : (RB == 6 ? 5 : (RB == 2 ? 2 : 3));  // per SIMD (launch bounds)
   // ... of the producer half of the decoupled path (qmpc_sweep_kernel): without the packed inverse its LDS is the
   // assembly / sweep storage only, so the 128-row class fits two workgroups per CU if it stays within 128 VGPRs
 #ifndef QMPC_SWEEP_WAVES2
@@ -1313,7 +1311,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   // (P^-1 C^T); since a_kj == c_j they get it from the same update with
   // F_k = I - P^-1, so the update has no row special-casing.
   bool notpd = false;
-  if constexpr (RB == 1) {
+  if constexpr (C::C1) {
     // Class 1: a column group is exactly one wave (lane == row), so the wave that
     // owns the NEXT pivot pair reads its 2x2 pivot block with readlane, inverts it
     // once, and publishes F = C P^-1 (with the pivot-row correction folded in) next
@@ -3237,7 +3235,7 @@ hipError_t prepare_class() {
   if ((e = set_smem(qmpc_solve_kernel<RB, true, false, false>, n)) != hipSuccess) return e;
   if ((e = set_smem(qmpc_solve_kernel<RB, false, true, false>, n)) != hipSuccess) return e;
   if ((e = set_smem(qmpc_admm_kernel<RB, false>, n)) != hipSuccess) return e;
-  if constexpr (RB != 1) {  // (class 1 is only ever launched first)
+  if constexpr (!Cfg<RB>::C1) {  // (class 1 is only ever launched first)
     if ((e = set_smem(qmpc_solve_kernel<RB, false, false, true>, n)) != hipSuccess) return e;
     if ((e = set_smem(qmpc_solve_kernel<RB, true, false, true>, n)) != hipSuccess) return e;
     if ((e = set_smem(qmpc_solve_kernel<RB, false, true, true>, n)) != hipSuccess) return e;
@@ -3297,7 +3295,7 @@ void launch_variant(bool cmd, const QmpcParams* P, int grid, hipStream_t stream)
 }
 template <int RB>
 void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
-  if constexpr (RB != 1) {
+  if constexpr (!Cfg<RB>::C1) {
     if (P->list) return launch_variant<RB, true>(cmd, P, grid, stream);
   }
   launch_variant<RB, false>(cmd, P, grid, stream);
@@ -3313,7 +3311,7 @@ int resident_class() {
   int dev = 0, cus = 0, per = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
-  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, qmpc_solve_kernel<RB, false, false, RB != 1>,
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, qmpc_solve_kernel<RB, false, false, !Cfg<RB>::C1>,
                                                                     Cfg<RB>::NT, sizeof(Smem<RB>));
   if (e != hipSuccess || per < 1 || cus < 1) return 0;
   return cached = per * cus;
@@ -3357,4 +3355,8 @@ extern "C" hipError_t qmpc_big_launch(const QmpcParams* P, int grid, hipStream_t
 #endif
 #if !defined(QMPC_RB) || QMPC_RB == 4
 QMPC_DEFINE_CLASS(4)
+#endif
+#if !defined(QMPC_RB) || QMPC_RB == 6
+static_assert(sizeof(Smem<6>) <= 32768, "64-row class at five workgroups per CU");
+QMPC_DEFINE_CLASS(6)
 #endif

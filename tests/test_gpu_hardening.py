@@ -188,3 +188,29 @@ def test_more_robots_than_work_items_same_results(mpc_factory):
                 assert np.array_equal(res[k], base[k]), (name, nch, k)
         m.set_chunks(0)
         assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+
+
+def test_dense_instantiation_of_the_64_row_class_is_bit_identical(mpc_factory):
+    """qmpc_set_dense: the 64-row class's five-workgroups-per-CU instantiation (96 VGPRs, 16 events in LDS) computes the
+    same arithmetic -- bit-identical forces, solutions, iteration counts -- as the four-per-CU one, also for the robots
+    whose event pool overflows earlier (16 instead of 28 events: they continue in the global pool, same records).  Mixed
+    gaits (up to 20+ iterations) and trot; the automatic mode takes it from 2048 robots per handle on, only when the
+    stance hint makes the 64-row class the whole chain."""
+    for b in (W.make_config(2, batch=1536), W.make_config(1, batch=700)):
+        nst = (b["gait"] != 0).sum(1)
+        m = mpc_factory(b)
+        m.set_max_stance(int(nst.max()))
+        m.set_dense(0)
+        base = m.solve(b, full=True)
+        assert ((base["status"] & 47) == 0).all()
+        m.set_dense(2)
+        res = m.solve(b, full=True)
+        for k in ("grf", "soln", "iters"):
+            assert np.array_equal(res[k], base[k]), k
+        assert np.array_equal(res["status"] & 47, base["status"] & 47)
+        spilled = int(((res["status"] & 128) != 0).sum())
+        print(f"   dense instantiation: B={b['batch']} iters max {res['iters'].max()}, robots continuing in the global pool "
+              f"{spilled} (four per CU: {int(((base['status'] & 128) != 0).sum())})")
+        # without the hint the chain has larger classes behind it: the automatic / forced mode leaves it alone
+        m.set_max_stance(0)
+        assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
