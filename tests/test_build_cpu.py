@@ -61,7 +61,7 @@ def test_cold_build_from_sources(tmp_path):
     lib = G.build(out_dir=out)
     assert os.path.dirname(lib) == out and os.path.getsize(lib) > 1 << 20
     objs = sorted(os.listdir(os.path.join(out, "obj")))
-    assert [o for o in objs if o.startswith("qmpc_kernels_c")] == [f"qmpc_kernels_c{rb}.o" for rb in (1, 2, 3, 4)]
+    assert [o for o in objs if o.startswith("qmpc_kernels_c")] == [f"qmpc_kernels_c{rb}.o" for rb in (1, 2, 3, 4, 6)]
     dll = C.CDLL(lib)
     for name in binding.EXPORTS:
         assert hasattr(dll, name), name
