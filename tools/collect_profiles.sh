@@ -13,7 +13,7 @@ cp gpurun_out/$T/shim_latency.json profiles/${T}_shim_latency.json
 cp gpurun_out/$T/warm_rollout.json profiles/${T}_warm_rollout.json
 cp gpurun_out/$T/class_stats.txt profiles/${T}_class_stats.txt 2>/dev/null || true
 for f in large_trot_h36 large_stand_h36; do cp gpurun_out/$T/kernel_stats_$f.csv profiles/${T}_kernel_stats_$f.csv 2>/dev/null || true; cp gpurun_out/$T/pmc_summary_$f.json profiles/${T}_pmc_summary_$f.json 2>/dev/null || true; done
-for f in split_check engine_phases sweep_phases jcqp_long; do cp gpurun_out/$T/$f.txt profiles/${T}_$f.txt 2>/dev/null || true; done
+for f in split_check engine_phases sweep_phases jcqp_long dense_threshold; do cp gpurun_out/$T/$f.txt profiles/${T}_$f.txt 2>/dev/null || true; done
 for f in long_trot_h24 long_bound_h36 large_trot_h36 large_standing_h24 large_stand_h36 standing_h10_one_kernel standing_h14_one_kernel standing_h16_one_kernel; do
   cp gpurun_out/$T/bench_$f.json profiles/${T}_bench_$f.json 2>/dev/null || true
 done

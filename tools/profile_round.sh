@@ -44,6 +44,7 @@ for w in "large_trot_h36 long-trot 36 30" "large_stand_h36 long-stand 36 20"; do
   rm -rf $OUT/pmc_$1/p[0-9]*
 done
 python $R/tools/jcqp_long.py 2>/dev/null | grep -v amdgpu > $OUT/jcqp_long.txt
+python $R/tools/dense_threshold.py 2>/dev/null | grep -v amdgpu > $OUT/dense_threshold.txt
 # the same standing workloads on the one-kernel path (before / after of the decoupled path in ONE profile set)
 for hh in 10 14 16; do
   QMPC_NO_SPLIT=1 python $R/bench.py --steps 200 --workload standing --horizon $hh --no-cpu-baseline --no-pipelined > $OUT/bench_standing_h${hh}_one_kernel.json 2>/dev/null
