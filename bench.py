@@ -468,6 +468,8 @@ def main():
         # template arguments: <size class, command mode, warm start, list-consuming>; the dominant kernel of a uniform
         # workload is the first of its chain (not list-consuming) -- the name rocprofv3 --kernel-trace --stats reports
         cm = 'true' if args.caller_side == 'fused' else 'false'
+        if kclass == 1 and per_gpu >= 2048 and not args.no_hint:
+            kclass = 6   # the 64-row class's five-workgroups-per-CU instantiation (qmpc_set_dense, automatic from 2048 robots per handle)
         kname = f"qmpc_solve_kernel<{kclass}, {cm}, false, false>"
         if kclass in (2, 3) and os.environ.get("QMPC_NO_SPLIT", "0") != "1":
             # decoupled path: the step is the sweep kernel, the engine kernel and the (normally empty) hand-back launch
