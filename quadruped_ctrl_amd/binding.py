@@ -488,7 +488,8 @@ class BatchedConvexMPC:
         self._check(self.lib.qmpc_set_block_start(self.h, int(bool(on))), "qmpc_set_block_start")
 
     def set_dense(self, mode):
-        """0 / 1 / 2: the 64-row class's five-workgroups-per-CU instantiation never / by the handle's size / always."""
+        """0 / 1 / 2: the 64-row class's five-workgroups-per-CU instantiation never / automatic (handles of 2048+ robots; see
+        include/qmpc.h) / whenever that class is the whole chain."""
         self._check(self.lib.qmpc_set_dense(self.h, int(mode)), "qmpc_set_dense")
 
     def set_chunks(self, n):

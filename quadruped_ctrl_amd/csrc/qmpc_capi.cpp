@@ -255,7 +255,9 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) {
     // a robot whose on-chip event pool fills up continues here; more than ov_nslice of them in one launch chain
     // fall back to the Schur-form engine
-    c->ov_nslice = max_batch < 1024 ? max_batch : 1024;
+    // (2048 slices of 192 KiB: what a call of 8192 robots needs when the 64-row class runs five per CU ahead of larger
+    //  classes -- see the launch loop of solve_impl)
+    c->ov_nslice = max_batch < 2048 ? max_batch : 2048;
     e = hipMalloc(&c->d_ovpool, sizeof(double) * (size_t)c->ov_nslice * QMPC_OV_SLICE);
   }
   if (e == hipSuccess) e = qmpc_prepare();
@@ -849,6 +851,12 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     // HANDLE's size, never the call's.  Not for chains with larger classes: their robots iterate long, and 16 events in LDS
     // instead of 28 send a thousand of them to the overflow pool (configs[4]: -40 %)
     int kcls = kChain[k];
+    // Chains with larger classes behind it (configs[4]: random contact tables): their robots iterate longer, and 16 events
+    // in LDS instead of 28 send about one in eight of them to the overflow pool -- with a slice for each of them (2048 per handle:
+    // calls of up to 8192 robots; results are bit-identical either way, so the CALL's size may decide here) the launch still
+    // gains: configs[4] 492 -> 482 us per 8192 robots (+2 %); with 1024 slices it lost 40 % to the Schur-form fallback
+    if (kcls == 1 && pl.k1 - pl.k0 > 1 && !pl.long_h && c->dense == 1 && c->max_batch >= 2048 && c->ov_nslice >= 2048 && batch <= 4 * c->ov_nslice)
+      kcls = 6;
     if (kcls == 1 && pl.k1 - pl.k0 == 1 && !pl.long_h && (c->dense == 2 || (c->dense == 1 && c->max_batch >= 2048))) kcls = 6;
     HIP_TRY(c, qmpc_launch(kcls, &P, grid, stream));
   }

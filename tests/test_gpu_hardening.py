@@ -64,8 +64,9 @@ def test_device_memory_is_bounded_for_a_65536_robot_handle(h):
     held = before - _free_bytes()
     m.close()
     torch.cuda.synchronize()
-    # the handle's pools are given back (what remains is torch's cache of this test's input / output tensors)
-    assert held - (before - _free_bytes()) > used - 64 * 2**20
+    # the handle's pools are given back (what remains is torch's cache of this test's input / output tensors and the HIP
+    # runtime's scratch arena for the kernels of this process that use scratch -- the Schur-form fallback instantiations)
+    assert held - (before - _free_bytes()) > used - 256 * 2**20
 
 
 @pytest.mark.parametrize("name", ["trot_h10", "trot_h16", "random_contacts_h10", "standing_h10_decoupled",
@@ -194,8 +195,8 @@ def test_dense_instantiation_of_the_64_row_class_is_bit_identical(mpc_factory):
     """qmpc_set_dense: the 64-row class's five-workgroups-per-CU instantiation (96 VGPRs, 16 events in LDS) computes the
     same arithmetic -- bit-identical forces, solutions, iteration counts -- as the four-per-CU one, also for the robots
     whose event pool overflows earlier (16 instead of 28 events: they continue in the global pool, same records).  Mixed
-    gaits (up to 20+ iterations) and trot; the automatic mode takes it from 2048 robots per handle on, only when the
-    stance hint makes the 64-row class the whole chain."""
+    gaits (up to 20+ iterations) and trot; the automatic mode takes it from 2048 robots per handle on (chains with larger
+    classes behind the 64-row class: calls of up to 8192 robots)."""
     for b in (W.make_config(2, batch=1536), W.make_config(1, batch=700)):
         nst = (b["gait"] != 0).sum(1)
         m = mpc_factory(b)
@@ -211,6 +212,21 @@ def test_dense_instantiation_of_the_64_row_class_is_bit_identical(mpc_factory):
         spilled = int(((res["status"] & 128) != 0).sum())
         print(f"   dense instantiation: B={b['batch']} iters max {res['iters'].max()}, robots continuing in the global pool "
               f"{spilled} (four per CU: {int(((base['status'] & 128) != 0).sum())})")
-        # without the hint the chain has larger classes behind it: the automatic / forced mode leaves it alone
+        # without the hint the chain has larger classes behind it: same results again
         m.set_max_stance(0)
         assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+    # a chain with larger classes behind the 64-row class (random contact tables: a third of the robots move on to the
+    # 96-row class): the automatic mode runs the first class five per CU for calls of up to 8192 robots on a handle of 2048+
+    b = W.make_config(4, batch=2048)
+    m = mpc_factory(b)
+    m.set_dense(0)
+    base = m.solve(b, full=True)
+    assert ((base["status"] & 47) == 0).all()
+    m.set_dense(1)
+    res = m.solve(b, full=True)
+    for k in ("grf", "soln", "iters"):
+        assert np.array_equal(res[k], base[k]), k
+    assert np.array_equal(res["status"] & 47, base["status"] & 47)
+    print(f"   chain (configs[4], 2048 robots): iters max {res['iters'].max()}, robots continuing in the global pool "
+          f"{int(((res['status'] & 128) != 0).sum())} (four per CU: {int(((base['status'] & 128) != 0).sum())}), handed back "
+          f"{int(((res['status'] & 16) != 0).sum())}")
