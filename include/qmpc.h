@@ -222,6 +222,15 @@ int qmpc_set_block_start(qmpc_handle h, int on);
  * classes behind it in the chain, for calls of up to 8192 robots (their overflow-pool slices: 2048 per handle; configs[4] + 2 %);
  * mode 0: never; mode 2: whenever the chain is that class alone.  Same arithmetic: bit-identical results (tested). */
 int qmpc_set_dense(qmpc_handle h, int mode);
+/* Order hint.  A launch of several rounds of workgroups ends with whichever hard robot started last.  A controller solves
+ * the SAME robots every MPC cycle, and a robot that needed many active-set iterations 26 ms ago needs many now: with
+ * mode 1 (default) every one-kernel solve leaves its iteration count in a per-handle array, and a call of the same batch
+ * size whose first size class is launched over more robots than it has resident workgroups takes the robots in the order
+ * of those counts, longest first (one counting-sort kernel of a few microseconds in front of the call).  Scheduling only:
+ * a robot's result does not depend on its place (bit-identical, tested); a stale or meaningless hint -- other robots in
+ * the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
+ * and the JCQP alternate do not use it. */
+int qmpc_set_order_hint(qmpc_handle h, int mode);
 /* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for
  * the 128-row class / 192-row class / large problems -- whatever max_batch is; a call with more robots than items runs the
  * class as consecutive chunks (producer kernel, engine kernel, producer kernel, ...) on the caller's stream, the pool reused

@@ -107,6 +107,28 @@ static hipError_t fill_ints(int* p, int n, int v, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Order hint: robots sorted by the iteration count of the handle's previous call, longest first (counting sort, one
+// workgroup; the order inside a bin is whatever the atomics make it -- a robot's result does not depend on its place)
+#define QMPC_HINT_BINS 64
+__global__ __launch_bounds__(1024) void qmpc_order_kernel(const int* __restrict__ it, int* __restrict__ order, int n) {
+  __shared__ int hist[QMPC_HINT_BINS];
+  if (threadIdx.x < QMPC_HINT_BINS) hist[threadIdx.x] = 0;
+  __syncthreads();
+  auto bin = [](int v) { return QMPC_HINT_BINS - 1 - (v < 0 ? 0 : (v > QMPC_HINT_BINS - 1 ? QMPC_HINT_BINS - 1 : v)); };
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bin(it[i])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < QMPC_HINT_BINS; ++b) {
+      const int cnt = hist[b];
+      hist[b] = acc;
+      acc += cnt;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&hist[bin(it[i])], 1)] = i;
+}
+
 struct qmpc_ctx {
   int device = 0;
   int max_batch = 0, max_horizon = 0;
@@ -136,6 +158,12 @@ struct qmpc_ctx {
   int chunks = 0;              // qmpc_set_chunks (test hook): run the item classes in at least this many chunks (0 / 1: as few as the pools allow)
   int dbg_engine_events = 0;   // test hook: events the engine may hold per robot (0 = the compiled capacity)
   unsigned call_no = 0;
+  // order hint (qmpc_set_order_hint): 0 off, 1 automatic -- a call whose first class is launched over more robots than it has
+  // resident workgroups takes them in the order of the previous call's iteration counts (same batch size), longest first
+  int order_hint = 1;
+  int* d_hint_iters = nullptr;  // [max_batch] iteration counts the one-kernel classes left in the previous call
+  int* d_order = nullptr;       // [max_batch] the permutation of this call
+  int hint_batch = 0;           // batch size of the call that wrote d_hint_iters (0: none yet)
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
   int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
@@ -224,7 +252,7 @@ int ensure_pools(qmpc_ctx* c);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 16; }
+int qmpc_abi_version(void) { return 17; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -246,6 +274,9 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 3 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 3 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 3 * (size_t)max_batch);
+  if (e == hipSuccess) e = hipMalloc(&c->d_hint_iters, sizeof(int) * 2 * (size_t)max_batch);
+  if (e == hipSuccess) e = hipMemset(c->d_hint_iters, 0, sizeof(int) * 2 * (size_t)max_batch);
+  if (e == hipSuccess) c->d_order = c->d_hint_iters + max_batch;
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = (ns && ns[0] == '1') ? 0 : 1;
@@ -281,6 +312,7 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_ovpool) hipFree(h->d_ovpool);
     if (h->d_evflags) hipFree(h->d_evflags);
     if (h->d_fb_lists) hipFree(h->d_fb_lists);
+    if (h->d_hint_iters) hipFree(h->d_hint_iters);
     for (int k = 0; k < 3; ++k) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
@@ -453,6 +485,13 @@ int qmpc_set_block_start(qmpc_handle c, int on) {
 int qmpc_set_dense(qmpc_handle c, int mode) {
   if (!c || mode < 0 || mode > 2) return QMPC_ERR_ARG;
   c->dense = mode;
+  return QMPC_OK;
+}
+
+int qmpc_set_order_hint(qmpc_handle c, int mode) {
+  if (!c || mode < 0 || mode > 1) return QMPC_ERR_ARG;
+  c->order_hint = mode;
+  c->hint_batch = 0;
   return QMPC_OK;
 }
 
@@ -694,6 +733,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_g = c->dbg_g;
   P.dbg_aux = c->dbg_aux;
   P.dbg_clk = c->dbg_clk;
+  P.hint_iters = (c->order_hint && !capturing) ? c->d_hint_iters : nullptr;
 
   P.ovpool = c->d_ovpool;
   P.ov_nslice = c->ov_nslice;
@@ -858,8 +898,19 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     if (kcls == 1 && pl.k1 - pl.k0 > 1 && !pl.long_h && c->dense == 1 && c->max_batch >= 2048 && c->ov_nslice >= 2048 && batch <= 4 * c->ov_nslice)
       kcls = 6;
     if (kcls == 1 && pl.k1 - pl.k0 == 1 && !pl.long_h && (c->dense == 2 || (c->dense == 1 && c->max_batch >= 2048))) kcls = 6;
+    // order hint: the first class of the chain, launched over more robots than it has resident workgroups (several rounds:
+    // the launch ends with whichever hard robot started last), takes the robots in the order of their iteration counts in the
+    // previous call -- the same robots one MPC cycle earlier -- longest first.  Results do not depend on the order.
+    P.order = nullptr;
+    if (!listed && c->order_hint && !capturing && !P.admm_mode && c->hint_batch == batch && batch > qmpc_resident_blocks(kcls)) {
+      hipLaunchKernelGGL(qmpc_order_kernel, dim3(1), dim3(1024), 0, stream, (const int*)c->d_hint_iters, c->d_order, batch);
+      HIP_TRY(c, hipGetLastError());
+      P.order = c->d_order;
+    }
     HIP_TRY(c, qmpc_launch(kcls, &P, grid, stream));
+    P.order = nullptr;
   }
+  if (c->order_hint && !capturing && !P.admm_mode) c->hint_batch = batch;
   if (pl.long_h) {
     // ---- the large problems (192 < n_r <= 432: all feet down beyond 16 segments, a trot beyond 32): H in global memory,
     // block sweep, the seven-block engine; what that engine cannot hold is REPORTED.  Normally the list is empty: launches

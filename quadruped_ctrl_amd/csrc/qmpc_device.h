@@ -177,6 +177,12 @@ struct QmpcParams {
   double* dbg_g;
   double* dbg_aux;     // [batch][8]: cos/sin(yaw), roll, pitch, yaw as the kernel evaluated them (float transcendentals)
   long long* dbg_clk;  // [batch][16] shader-clock stamps per phase
+  // order hint (qmpc_set_order_hint; both nullptr = off): the first class of the chain takes robot order[blockIdx.x]
+  // instead of blockIdx.x -- the robots that iterated longest in the handle's previous call first, so that a launch of
+  // several rounds of workgroups does not end with a hard robot that started last -- and every one-kernel solve
+  // leaves its iteration count in hint_iters[robot] for the next call's order
+  const int32_t* order;
+  int32_t* hint_iters;
 };
 
 #endif

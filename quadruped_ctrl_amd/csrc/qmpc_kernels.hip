@@ -2554,6 +2554,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         if (lane == 0) {
           P.status[rid] = S.status | status;
           if (P.iters) P.iters[rid] = iters;
+          if (P.hint_iters) P.hint_iters[rid] = iters;
           if (cmdm) cmd_finish_state();
         }
         if (WARM && P.ws)  // the final working set, as global ids, for the next cycle's warm start
@@ -2983,6 +2984,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     if (lane == 0) {
       P.status[rid] = S.status | status;
       if (P.iters) P.iters[rid] = iters;
+      if (P.hint_iters) P.hint_iters[rid] = iters;
       if (cmdm) cmd_finish_state();
     }
     if (WARM && P.ws)  // (this engine always starts cold; it still leaves its working set for the next cycle)
@@ -3089,7 +3091,9 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
     if (blockIdx.x == 0 && P.clear_counts)
       for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;  // 3 counters + 3 heads
     pool_acquire<RB>(S, P);
-    solve_robot<RB, CMD, WARM>((int)blockIdx.x, (int)threadIdx.x, S, P);
+    // (order hint: the previous call's hardest robots first; results do not depend on the order)
+    const int rid = P.order ? __builtin_amdgcn_readfirstlane(P.order[blockIdx.x]) : (int)blockIdx.x;
+    solve_robot<RB, CMD, WARM>(rid, (int)threadIdx.x, S, P);
     pool_release<RB>(S, P);
   } else {
     const int nlist = *P.count;

@@ -230,3 +230,43 @@ def test_dense_instantiation_of_the_64_row_class_is_bit_identical(mpc_factory):
     print(f"   chain (configs[4], 2048 robots): iters max {res['iters'].max()}, robots continuing in the global pool "
           f"{int(((res['status'] & 128) != 0).sum())} (four per CU: {int(((base['status'] & 128) != 0).sum())}), handed back "
           f"{int(((res['status'] & 16) != 0).sum())}")
+
+
+def test_order_hint_changes_the_order_not_the_results(mpc_factory):
+    """qmpc_set_order_hint: a call whose first size class is launched over more robots than it has resident workgroups takes
+    the robots in the order of the iteration counts the handle's previous call left (hardest first).  Scheduling only:
+    forces, solutions, iteration counts and status are bit-identical to the plain order -- with an exact hint (same inputs as
+    the call before), with a stale one (other robots in the same rows), after a call of another batch size (no hint used),
+    on a chain with larger classes behind the first one, and with the warm start."""
+    import torch
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC
+    for b, stance in ((W.make_config(2, batch=3000), True), (W.make_config(4, batch=2500), False), (W.make_config(3, batch=1100), True)):
+        B = int(b["batch"])
+        m = mpc_factory(b)
+        if stance:
+            m.set_max_stance(int((b["gait"] != 0).sum(1).max()))
+            m.set_min_stance(int((b["gait"] != 0).sum(1).min()))
+        m.set_order_hint(0)
+        base = m.solve(b, full=True)
+        assert ((base["status"] & 47) == 0).all()
+        m.set_order_hint(1)
+        first = m.solve(b, full=True)    # no hint yet: plain order, leaves the counts
+        exact = m.solve(b, full=True)    # ordered by exact counts
+        for res in (first, exact):
+            for k in ("grf", "soln", "iters"):
+                assert np.array_equal(res[k], base[k]), k
+            assert np.array_equal(res["status"] & 47, base["status"] & 47)
+        # a stale hint: the same rows now hold other robots (the batch reversed)
+        rb = {k: (v[::-1].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in b.items()}
+        stale = m.solve(rb, full=True)
+        for k in ("grf", "soln", "iters"):
+            assert np.array_equal(stale[k], base[k][::-1]), k
+        # another batch size in between: that call and the next use no hint
+        half = {k: (v[: B // 2].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in b.items()}
+        half["batch"] = B // 2
+        hres = m.solve(half, full=True)
+        assert np.array_equal(hres["soln"], base["soln"][: B // 2])
+        again = m.solve(b, full=True)
+        assert np.array_equal(again["soln"], base["soln"]) and np.array_equal(again["iters"], base["iters"])
+        print(f"   order hint: B={B} h={b['horizon']} iters mean {base['iters'].mean():.2f} max {base['iters'].max()}: bit-identical "
+              f"(exact / stale / after a call of another size)")
