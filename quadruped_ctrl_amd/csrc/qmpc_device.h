@@ -183,6 +183,16 @@ struct QmpcParams {
   // leaves its iteration count in hint_iters[robot] for the next call's order
   const int32_t* order;
   int32_t* hint_iters;
+  // ... and in a launch of ONE round of workgroups (the order cannot matter: everybody starts at once) a robot the previous
+  // call found hard keeps the highest issue priority through its sweep instead of yielding as it advances: of the workgroups
+  // that share a CU, the one that will iterate longest finishes its fixed part first.  Hard = at least hint_hard iterations
+  // (0 = off) and at least 3/5 of the previous call's maximum, *hint_max_r.  In a one-round launch the robots finish in the order
+  // of their iteration counts, so every solve simply stores its count to *hint_max_w and the last store is the maximum (a
+  // heuristic: no atomic); the first workgroup of the call clears *hint_max_z for the next call (three slots, rotated by the host)
+  int hint_hard;
+  const int32_t* hint_max_r;
+  int32_t* hint_max_w;
+  int32_t* hint_max_z;
 };
 
 #endif

@@ -347,6 +347,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #if QMPC_SWEEP_PRIO && QMPC_START_PRIO
   __builtin_amdgcn_s_setprio(3);  // a workgroup that is just starting is behind everybody else on its CU
 #endif
+  // order hint, single-round launches: a robot the previous call found hard (wave-uniform: two scalar loads)
+  bool hard = false;
+  if (PK.hint_hard > 0) {
+    const int mine = __builtin_amdgcn_readfirstlane(PK.hint_iters[rid]);
+    const int top = __builtin_amdgcn_readfirstlane(*PK.hint_max_r);
+    hard = mine >= PK.hint_hard && 5 * mine >= 3 * top;
+  }
 
   // ------------------------------------------------------------ stage 0
   // Every global load of the robot's record is issued up front (one memory
@@ -1379,7 +1386,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // dispatched used to sweep at full speed (24k cycles) and the last one at half
       // (50k) -- and a launch ends with its slowest workgroup.  A wave that is ahead now
       // yields to the ones behind it.
-      if (kb == 0) __builtin_amdgcn_s_setprio(3);
+      if (kb == 0 || hard) __builtin_amdgcn_s_setprio(3);
       else if (kb == 1) __builtin_amdgcn_s_setprio(2);
       else if (kb == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
@@ -1479,7 +1486,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     for (int kb = 0; kb < 4; ++kb) {
 #if QMPC_SWEEP_PRIO
       // see the class-1 loop: a wave that is ahead yields issue slots to the ones behind it
-      if (kb == 0) __builtin_amdgcn_s_setprio(3);
+      if (kb == 0 || hard) __builtin_amdgcn_s_setprio(3);
       else if (kb == 1) __builtin_amdgcn_s_setprio(2);
       else if (kb == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
@@ -2555,6 +2562,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           P.status[rid] = S.status | status;
           if (P.iters) P.iters[rid] = iters;
           if (P.hint_iters) P.hint_iters[rid] = iters;
+          if (P.hint_max_w) *P.hint_max_w = iters;  // (one round: the robot that finishes last is the hardest; a plain store, no atomic on anybody's critical path)
           if (cmdm) cmd_finish_state();
         }
         if (WARM && P.ws)  // the final working set, as global ids, for the next cycle's warm start
@@ -2985,6 +2993,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       P.status[rid] = S.status | status;
       if (P.iters) P.iters[rid] = iters;
       if (P.hint_iters) P.hint_iters[rid] = iters;
+      if (P.hint_max_w) *P.hint_max_w = iters;  // (one round: the robot that finishes last is the hardest; a plain store, no atomic on anybody's critical path)
       if (cmdm) cmd_finish_state();
     }
     if (WARM && P.ws)  // (this engine always starts cold; it still leaves its working set for the next cycle)
@@ -3090,6 +3099,7 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
     // (block index first: only block 0 waits for the kernel argument)
     if (blockIdx.x == 0 && P.clear_counts)
       for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;  // 3 counters + 3 heads
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.hint_max_z) *P.hint_max_z = 0;
     pool_acquire<RB>(S, P);
     // (order hint: the previous call's hardest robots first; results do not depend on the order)
     const int rid = P.order ? __builtin_amdgcn_readfirstlane(P.order[blockIdx.x]) : (int)blockIdx.x;

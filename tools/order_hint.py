@@ -108,20 +108,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cycles", type=int, default=24)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--static-only", action="store_true")
     a = ap.parse_args()
     out = {"static": [], "rollout": []}
     jobs = [("configs[2] mixed gaits 4096", W.make_config(2), 60), ("configs[3] trot h16, 4096 per GPU", W.make_config(3, batch=4096), 30),
             ("configs[4] random contacts, 8192 per GPU", W.make_config(4, batch=8192), 30)]
+    jobs += [("configs[1] trot, batch 1024", W.make_config(1), 200)]
     if not a.quick:
-        jobs += [("configs[1] trot, batch 1024", W.make_config(1), 200), ("trot h10, batch 16384", W.make_config(1, batch=16384), 30),
+        jobs += [("trot h10, batch 16384", W.make_config(1, batch=16384), 30),
                  ("configs[2] at 8192", W.make_config(2, batch=8192), 40)]
     for name, b, steps in jobs:
         r = static(name, b, steps)
         out["static"].append(r)
         print(f"# {name:44s} {r['qps_plain']:.3e} -> {r['qps_hint']:.3e} QP/s ({100 * r['gain']:+.1f} %)  iters {r['iters_mean']:.2f}/{r['iters_max']}  "
               f"bit-identical {r['bit_identical']}  failed {r['failed']}", file=sys.stderr)
-    ros = [("mixed", 10, 4096), ("trot", 16, 4096)] + ([] if a.quick else [("mixed", 10, 8192), ("trot", 10, 8192)])
-    for gait, h, B in ros:
+    ros = [("mixed", 10, 4096), ("trot", 16, 4096), ("trot", 10, 1024), ("mixed", 10, 1024)] + ([] if a.quick else [("mixed", 10, 8192), ("trot", 10, 8192), ("trot", 16, 512)])
+    for gait, h, B in ([] if a.static_only else ros):
         r = rollout(gait, h, B, a.cycles)
         out["rollout"].append(r)
         print(f"# {r['scenario']:36s} B={B}: {r['plain_ms']:.4f} -> {r['hint_ms']:.4f} ms/cycle ({100 * r['gain']:+.1f} %)  iters {r['iters_mean']:.2f}/{r['iters_max']}  "
