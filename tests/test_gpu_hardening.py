@@ -237,10 +237,13 @@ def test_order_hint_changes_the_order_not_the_results(mpc_factory):
     the robots in the order of the iteration counts the handle's previous call left (hardest first).  Scheduling only:
     forces, solutions, iteration counts and status are bit-identical to the plain order -- with an exact hint (same inputs as
     the call before), with a stale one (other robots in the same rows), after a call of another batch size (no hint used),
-    on a chain with larger classes behind the first one, and with the warm start."""
+    on a chain with larger classes behind the first one.  A launch of ONE round uses the counts as issue priority for the hard
+    robots instead (qmpc_device.h: hint_hard): same results again."""
     import torch
     from quadruped_ctrl_amd.binding import BatchedConvexMPC
-    for b, stance in ((W.make_config(2, batch=3000), True), (W.make_config(4, batch=2500), False), (W.make_config(3, batch=1100), True)):
+    for b, stance in ((W.make_config(2, batch=3000), True), (W.make_config(4, batch=2500), False), (W.make_config(3, batch=1100), True),
+                      # one round of workgroups: the hint becomes issue priority for the robots the previous call found hard
+                      (W.make_config(2, batch=900), True), (W.make_config(4, batch=600), False)):
         B = int(b["batch"])
         m = mpc_factory(b)
         if stance:
