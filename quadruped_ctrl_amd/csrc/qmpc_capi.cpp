@@ -167,6 +167,7 @@ struct qmpc_ctx {
   int hint_hard = 5;            // single-round launches: iterations in the previous call from which a robot may keep the highest issue priority (0 = off)
   int* d_hint_max = nullptr;    // [3] largest iteration count of the last calls (slots rotated by hint_call: read / fold / clear)
   unsigned hint_call = 0;
+  int* d_cu_slots = nullptr;
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
   int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
@@ -277,10 +278,11 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 3 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 3 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMalloc(&c->d_fb_lists, sizeof(int) * 3 * (size_t)max_batch);
-  if (e == hipSuccess) e = hipMalloc(&c->d_hint_iters, sizeof(int) * (2 * (size_t)max_batch + 4));
-  if (e == hipSuccess) e = hipMemset(c->d_hint_iters, 0, sizeof(int) * (2 * (size_t)max_batch + 4));
+  if (e == hipSuccess) e = hipMalloc(&c->d_hint_iters, sizeof(int) * (2 * (size_t)max_batch + 4 + 2048));
+  if (e == hipSuccess) e = hipMemset(c->d_hint_iters, 0, sizeof(int) * (2 * (size_t)max_batch + 4 + 2048));
   if (e == hipSuccess) c->d_order = c->d_hint_iters + max_batch;
   if (e == hipSuccess) c->d_hint_max = c->d_hint_iters + 2 * (size_t)max_batch;
+  if (e == hipSuccess) c->d_cu_slots = c->d_hint_max + 4;  // [2048] the 96-row class's per-CU placement words (zero whenever no kernel runs)
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = (ns && ns[0] == '1') ? 0 : 1;
@@ -740,6 +742,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_aux = c->dbg_aux;
   P.dbg_clk = c->dbg_clk;
   P.hint_iters = (c->order_hint && !capturing) ? c->d_hint_iters : nullptr;
+  P.cu_slots = c->d_cu_slots;
 
   P.ovpool = c->d_ovpool;
   P.ov_nslice = c->ov_nslice;

@@ -189,6 +189,8 @@ struct QmpcParams {
   // (0 = off) and at least 3/5 of the previous call's maximum, *hint_max_r.  In a one-round launch the robots finish in the order
   // of their iteration counts, so every solve simply stores its count to *hint_max_w and the last store is the maximum (a
   // heuristic: no atomic); the first workgroup of the call clears *hint_max_z for the next call (three slots, rotated by the host)
+  // the 96-row class's wave placement (qmpc_kernels.hip: balance_waves): one int per CU, [xcc 3 bits][se, sh, cu 8 bits]
+  int* cu_slots;
   int hint_hard;
   const int32_t* hint_max_r;
   int32_t* hint_max_w;

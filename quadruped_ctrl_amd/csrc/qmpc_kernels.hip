@@ -187,6 +187,18 @@ struct Cfg {
   static constexpr int NP = (RB == 4) ? 96 : (RB == 6 ? 64 : 64 * RB);
   static constexpr int CW = NP / 4;
   static constexpr int NT = 4 * NP;
+  // The 96-row class's workgroup is SIX waves, which the dispatcher lays (1,2,1,2)-style over the four SIMDs; two such
+  // workgroups per CU never complement each other -- the per-CU totals are always a permutation of (4,3,3,2)
+  // (tools/ubench/simd_place.hip) and the SIMD with four waves sets the pace of both workgroups (a barrier per pivot pair).
+  // Its solve kernels are therefore LAUNCHED with eight waves (two per SIMD, always), look where they landed
+  // (HW_REG_HW_ID), and two of them exit at once: the workgroup keeps both waves on two SIMDs and one on the other two,
+  // WHICH two decided per CU (a two-bit slot word per CU in global memory) so that the two residents complement each
+  // other: (3,3,3,3).  balance_waves() below
+#ifndef QMPC_BALANCE4
+#define QMPC_BALANCE4 1
+#endif
+  static constexpr bool BALANCE = QMPC_BALANCE4 && (RB == 4);
+  static constexpr int NT_LAUNCH = BALANCE ? 512 : NT;
   static constexpr int RE = (NP + 63) / 64;  // 64-row blocks of an index-major engine vector
   // Schur-form engine (the fallback): working-set slots.  Every n_r <= 64 problem fits 64; in the largest
   // class the 160 KiB of LDS next to the packed inverse set the bound at run time (48 slots at
@@ -251,6 +263,7 @@ struct Smem {
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   int evslot;  // class 3: this workgroup's slice of the global event pool
   int qnext;   // next entry of the work list (classes launched after the first)
+  int bal_simd[8], bal_cu, bal_bit;  // balance_waves: where the launched waves landed, this CU's slot word, the bit taken
   // the engine wave's request to the helper waves (event-form engine, classes with NHELP > 0)
   struct Help {
     int cmd;  // 0 = the solve is over, 1 = accumulate your share of the events
@@ -3047,6 +3060,61 @@ __device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<R
   if (P.status_or != 0 && tid == 0) P.status[rid] |= P.status_or;
 }
 
+// The 96-row class (Cfg<4>::BALANCE): eight waves launched, six stay.  Returns the LOGICAL thread index (wave rank among
+// the survivors x 64 + lane), or -1 for a wave that must exit.  One barrier, taken by all eight waves; the hardware drops
+// a terminated wave from every later barrier.  P.cu_slots: one int per CU (xcc, se, sh, cu), bit 0 / bit 1 = a resident
+// workgroup keeps its pairs on SIMDs {0,1} / {2,3}; taken with atomicOr here, released by balance_release at the end.
+// Anything unexpected (a placement other than two waves per SIMD, no free bit, no slot array) falls back to "waves 0..5
+// stay", which is what a 384-thread launch does.
+template <int RB>
+__device__ __forceinline__ int balance_waves(Smem<RB>& S, const QmpcParams& P) {
+  if constexpr (!Cfg<RB>::BALANCE) {
+    return (int)threadIdx.x;
+  } else {
+    const int pw = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (lane == 0) S.bal_simd[pw] = (int)((hwid >> 4) & 3u);
+    if (threadIdx.x == 0) {
+      int bit = 0;
+      const int cu = (int)(((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu));
+      if (P.cu_slots) {
+        if (!(atomicOr(&P.cu_slots[cu], 1) & 1)) bit = 1;
+        else if (!(atomicOr(&P.cu_slots[cu], 2) & 2)) bit = 2;
+      }
+      S.bal_cu = cu;
+      S.bal_bit = bit;
+    }
+    __syncthreads();
+    const int pairs_hi = (S.bal_bit == 2) ? 1 : 0;  // 1: both waves stay on SIMDs 2 and 3, one each on 0 and 1
+    int seen[4] = {0, 0, 0, 0};
+    unsigned keep = 0u;
+    bool regular = true;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const int sd = S.bal_simd[w] & 3;
+      int cnt = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cnt = (sd == q) ? seen[q] : cnt;
+      const bool paired = ((sd >> 1) == pairs_hi);
+      if (cnt == 0 || (cnt == 1 && paired)) keep |= 1u << w;
+      if (cnt >= 2) regular = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) seen[q] += (sd == q) ? 1 : 0;
+    }
+    if (!regular || __builtin_popcount(keep) != 6) keep = 0x3fu;
+    if (!((keep >> pw) & 1u)) return -1;
+    return 64 * __builtin_popcount(keep & ((1u << pw) - 1u)) + lane;
+  }
+}
+template <int RB>
+__device__ __forceinline__ void balance_release(int tid, Smem<RB>& S, const QmpcParams& P) {
+  if constexpr (Cfg<RB>::BALANCE) {
+    if (tid == 0 && S.bal_bit != 0) atomicAnd(&P.cu_slots[S.bal_cu], ~S.bal_bit);
+  }
+}
+
 // class 3: take a slice of the global event pool for the lifetime of the workgroup: slot = workgroup index
 // modulo the slice count, guarded by a flag (a workgroup whose predecessor on that slice is still running --
 // it would have to be ~ev_nslot / 256 times slower than average -- waits for it).  The wait is bounded (a flag
@@ -3092,28 +3160,35 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
 // hands out.  (A grid of `batch` workgroups of which most find no entry costs more than the few solves
 // themselves: the no-op workgroups are dispatched at this class's LDS-limited occupancy.)
 template <int RB, bool CMD, bool WARM = false, bool LISTED = false>
-__global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
+__global__ __launch_bounds__(Cfg<RB>::NT_LAUNCH, Cfg<RB>::MIN_WAVES) void qmpc_solve_kernel(const QmpcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char qmpc_smem[];
   Smem<RB>& S = *reinterpret_cast<Smem<RB>*>(qmpc_smem);
+  // (the 96-row class: eight waves launched, six stay -- the logical thread index from here on)
+  const int tid0 = balance_waves<RB>(S, P);
+  if (tid0 < 0) return;
   if constexpr (!LISTED) {
     // (block index first: only block 0 waits for the kernel argument)
     if (blockIdx.x == 0 && P.clear_counts)
-      for (int k = threadIdx.x; k < QMPC_COUNTERS; k += blockDim.x) P.clear_counts[k] = 0;  // 3 counters + 3 heads
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.hint_max_z) *P.hint_max_z = 0;
+      for (int k = tid0; k < QMPC_COUNTERS; k += Cfg<RB>::NT) P.clear_counts[k] = 0;  // 3 counters + 3 heads
+    if (blockIdx.x == 0 && tid0 == 0 && P.hint_max_z) *P.hint_max_z = 0;
     pool_acquire<RB>(S, P);
     // (order hint: the previous call's hardest robots first; results do not depend on the order)
     const int rid = P.order ? __builtin_amdgcn_readfirstlane(P.order[blockIdx.x]) : (int)blockIdx.x;
-    solve_robot<RB, CMD, WARM>(rid, (int)threadIdx.x, S, P);
+    solve_robot<RB, CMD, WARM>(rid, tid0, S, P);
     pool_release<RB>(S, P);
+    balance_release<RB>(tid0, S, P);
   } else {
     const int nlist = *P.count;
-    if ((int)blockIdx.x >= nlist) return;  // uniform
+    if ((int)blockIdx.x >= nlist) {  // uniform
+      balance_release<RB>(tid0, S, P);
+      return;
+    }
     pool_acquire<RB>(S, P);
     for (int idx = (int)blockIdx.x;;) {
       const int rid = P.list[idx];
       // opaque thread id per robot: nothing derived from it is loop-invariant, so the compiler cannot hoist
       // per-thread values out of the loop (and spill them across the whole solve)
-      int tid1 = (int)threadIdx.x;
+      int tid1 = tid0;
 #if QMPC_LISTED_VARIANT >= 1
       asm volatile("" : "+v"(tid1));
       __builtin_assume(tid1 >= 0 && tid1 < Cfg<RB>::NT);
@@ -3131,12 +3206,13 @@ __global__ __launch_bounds__(Cfg<RB>::NT, Cfg<RB>::MIN_WAVES) void qmpc_solve_ke
       solve_robot<RB, CMD, WARM>(rid, tid1, S, P);
 #endif
       __syncthreads();  // every wave is done with this robot's LDS state
-      if (threadIdx.x == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
+      if (tid0 == 0) S.qnext = (int)gridDim.x + atomicAdd(P.qhead, 1);
       __syncthreads();
       idx = S.qnext;
       if (idx >= nlist) break;  // uniform
     }
     pool_release<RB>(S, P);
+    balance_release<RB>(tid0, S, P);
   }
 }
 
@@ -3296,16 +3372,16 @@ int resident_sweep() {
 }
 template <int RB, bool LISTED>
 void launch_variant(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
-  const dim3 g(grid), b(Cfg<RB>::NT);
+  const dim3 g(grid), b(Cfg<RB>::NT), bs(Cfg<RB>::NT_LAUNCH);  // (the solve kernels of the 96-row class: eight waves launched, six stay)
   const size_t n = sizeof(Smem<RB>);
   if (P->admm_mode)
     hipLaunchKernelGGL((qmpc_admm_kernel<RB, LISTED>), g, b, n, stream, *P);
   else if (P->ws && !cmd)  // warm start across cycles: its own instantiation (record mode)
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, true, LISTED>), g, b, n, stream, *P);
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, true, LISTED>), g, bs, n, stream, *P);
   else if (cmd)
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true, false, LISTED>), g, b, n, stream, *P);
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, true, false, LISTED>), g, bs, n, stream, *P);
   else
-    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, false, LISTED>), g, b, n, stream, *P);
+    hipLaunchKernelGGL((qmpc_solve_kernel<RB, false, false, LISTED>), g, bs, n, stream, *P);
 }
 template <int RB>
 void launch_one(bool cmd, const QmpcParams* P, int grid, hipStream_t stream) {
@@ -3326,7 +3402,7 @@ int resident_class() {
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     return 0;
   const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, qmpc_solve_kernel<RB, false, false, !Cfg<RB>::C1>,
-                                                                    Cfg<RB>::NT, sizeof(Smem<RB>));
+                                                                    Cfg<RB>::NT_LAUNCH, sizeof(Smem<RB>));
   if (e != hipSuccess || per < 1 || cus < 1) return 0;
   return cached = per * cus;
 }
