@@ -117,13 +117,15 @@ __global__ __launch_bounds__(1024) void qmpc_order_kernel(const int* __restrict_
   auto bin = [](int v) { return QMPC_HINT_BINS - 1 - (v < 0 ? 0 : (v > QMPC_HINT_BINS - 1 ? QMPC_HINT_BINS - 1 : v)); };
   for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bin(it[i])], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int b = 0; b < QMPC_HINT_BINS; ++b) {
-      const int cnt = hist[b];
-      hist[b] = acc;
-      acc += cnt;
+  if (threadIdx.x < QMPC_HINT_BINS) {  // exclusive prefix over the 64 bins: one wave, six shuffle steps
+    const int cnt = hist[threadIdx.x];
+    int acc = cnt;
+#pragma unroll
+    for (int d = 1; d < QMPC_HINT_BINS; d <<= 1) {
+      const int up = __shfl_up(acc, d);
+      if ((int)threadIdx.x >= d) acc += up;
     }
+    hist[threadIdx.x] = acc - cnt;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&hist[bin(it[i])], 1)] = i;

@@ -648,6 +648,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
   __syncthreads();  // ---- barrier 1
   QMPC_TICK(1);
+#if QMPC_SWEEP_PRIO && QMPC_START_PRIO
+  // one-round launch with the order hint: everybody started at the highest priority (a tie); from here to the sweep the
+  // robots the previous call did not find hard step back one level (the hint's two scalar loads have landed with the record)
+  if (PK.hint_hard > 0 && !hard) __builtin_amdgcn_s_setprio(2);
+#endif
   const int nst = S.nst;
   const int n = 3 * nst;
   // command mode: what the thread that finalises a robot does besides the outputs --
