@@ -362,10 +362,22 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #endif
   // order hint, single-round launches: a robot the previous call found hard (wave-uniform: two scalar loads)
   bool hard = false;
+  int hfloor = 0;  // the priority the robot does not fall below while it sweeps
   if (PK.hint_hard > 0) {
-    const int mine = __builtin_amdgcn_readfirstlane(PK.hint_iters[rid]);
+    // hard = at least hint_hard iterations, at least 3/5 of the previous call's maximum, AND among the top two of the sixteen
+    // robots of its aligned group (one 64-byte scalar load): where every robot iterates about equally long nobody is
+    // singled out and the staging below stays what it is -- everybody at the top priority is no staging at all (-13 %)
+    const int32_t* grp = (const int32_t*)__builtin_assume_aligned(PK.hint_iters + (rid & ~15), 64);
+    int mine = 0, ge = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine = ((rid & 15) == k) ? grp[k] : mine;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ge += (grp[k] >= mine) ? 1 : 0;
+    mine = __builtin_amdgcn_readfirstlane(mine);
+    ge = __builtin_amdgcn_readfirstlane(ge);
     const int top = __builtin_amdgcn_readfirstlane(*PK.hint_max_r);
-    hard = mine >= PK.hint_hard && 5 * mine >= 3 * top;
+    hard = mine >= PK.hint_hard && 5 * mine >= 3 * top && ge <= 2;
+    hfloor = hard ? 3 : ((mine >= PK.hint_hard && 5 * mine >= 2 * top && ge <= 4) ? 2 : 0);
   }
 
   // ------------------------------------------------------------ stage 0
@@ -1404,8 +1416,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // dispatched used to sweep at full speed (24k cycles) and the last one at half
       // (50k) -- and a launch ends with its slowest workgroup.  A wave that is ahead now
       // yields to the ones behind it.
-      if (kb == 0 || hard) __builtin_amdgcn_s_setprio(3);
-      else if (kb == 1) __builtin_amdgcn_s_setprio(2);
+      if (hard || (kb == 0 && PK.hint_hard <= 0)) __builtin_amdgcn_s_setprio(3);
+      else if (kb <= 1 || hfloor >= 2) __builtin_amdgcn_s_setprio(2);
       else if (kb == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1504,8 +1516,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     for (int kb = 0; kb < 4; ++kb) {
 #if QMPC_SWEEP_PRIO
       // see the class-1 loop: a wave that is ahead yields issue slots to the ones behind it
-      if (kb == 0 || hard) __builtin_amdgcn_s_setprio(3);
-      else if (kb == 1) __builtin_amdgcn_s_setprio(2);
+      if (hard || (kb == 0 && PK.hint_hard <= 0)) __builtin_amdgcn_s_setprio(3);
+      else if (kb <= 1 || hfloor >= 2) __builtin_amdgcn_s_setprio(2);
       else if (kb == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
 #endif
