@@ -924,7 +924,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
           HIP_TRY(c, hipGetLastError());
           P.order = c->d_order;
         }
-      } else {
+      } else if (2 * batch > qmpc_resident_blocks(kcls)) {  // (workgroups share CUs: below that priority has nobody to act on)
         // the largest count of the previous one-round call / of this one / cleared for the next: three slots in rotation
         const unsigned hc = c->hint_call++;
         P.hint_max_r = c->d_hint_max + (hc + 2) % 3;

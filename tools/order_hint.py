@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--cycles", type=int, default=24)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--static-only", action="store_true")
+    ap.add_argument("--single-round", action="store_true", help="one-round launches of other workloads (the priority side of the hint)")
     a = ap.parse_args()
     out = {"static": [], "rollout": []}
     jobs = [("configs[2] mixed gaits 4096", W.make_config(2), 60), ("configs[3] trot h16, 4096 per GPU", W.make_config(3, batch=4096), 30),
@@ -117,6 +118,13 @@ def main():
     if not a.quick:
         jobs += [("trot h10, batch 16384", W.make_config(1, batch=16384), 30),
                  ("configs[2] at 8192", W.make_config(2, batch=8192), 40)]
+    if a.single_round:
+        jobs = [("configs[1] trot, batch 1024", W.make_config(1), 200), ("mixed gaits, batch 1024", W.make_config(2, batch=1024), 100),
+                ("mixed gaits, batch 1280 (handle of 4096)", W.make_config(2, batch=1280), 100),
+                ("random contacts, batch 1024", W.make_config(4, batch=1024), 60), ("trot h16, batch 512", W.make_config(3, batch=512), 60),
+                ("trot, batch 512", W.make_config(1, batch=512), 200), ("trot, batch 256", W.make_config(1, batch=256), 200),
+                ("standing h10, batch 256 (one-kernel path)", W.make_standing(256, 10), 40),
+                ("standing h10 calm, batch 256", W.make_standing(256, 10, calm=True), 40)]
     for name, b, steps in jobs:
         r = static(name, b, steps)
         out["static"].append(r)
