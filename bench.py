@@ -517,7 +517,7 @@ def main():
                            "exact_in_this_bench": True if args.order_hint == "auto" else None,
                            "note": "every step re-solves the same inputs, so the previous call's counts are exact; closed-loop rollouts, "
                                    "where they are the previous MPC cycle's (correlation 0.6 - 0.8), gain about the same: "
-                                   "profiles/r04_r_order_hint.txt",
+                                   "profiles/r04_s_order_hint.txt",
                            "plain_order": plain_order},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

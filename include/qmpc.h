@@ -226,7 +226,9 @@ int qmpc_set_dense(qmpc_handle h, int mode);
  * the SAME robots every MPC cycle, and a robot that needed many active-set iterations 26 ms ago needs many now: with
  * mode 1 (default) every one-kernel solve leaves its iteration count in a per-handle array, and a call of the same batch
  * size whose first size class is launched over more robots than it has resident workgroups takes the robots in the order
- * of those counts, longest first (one counting-sort kernel of a few microseconds in front of the call).  Scheduling only:
+ * of those counts, longest first (one counting-sort kernel of a few microseconds in front of the call); a launch of ONE round
+ * (everybody starts at once) uses them as issue priority instead: the few robots the previous call found hardest keep the
+ * highest priority through their Gauss-Jordan sweep, so the launch no longer waits for them.  Scheduling only:
  * a robot's result does not depend on its place (bit-identical, tested); a stale or meaningless hint -- other robots in
  * the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
  * and the JCQP alternate do not use it. */
