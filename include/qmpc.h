@@ -233,6 +233,10 @@ int qmpc_set_dense(qmpc_handle h, int mode);
  * the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
  * and the JCQP alternate do not use it. */
 int qmpc_set_order_hint(qmpc_handle h, int mode);
+/* Test hook.  The 96-row class's solve kernels are launched with eight waves of which six stay, chosen so that the two
+ * workgroups of a CU load its four SIMDs evenly.  mode 1: every workgroup makes the same choice (no per-CU
+ * slot word); mode 2: the fallback "waves 0..5 stay"; mode 0 (default): balanced.  Results are bit-identical in all three. */
+int qmpc_set_debug_balance(qmpc_handle h, int mode);
 /* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for
  * the 128-row class / 192-row class / large problems -- whatever max_batch is; a call with more robots than items runs the
  * class as consecutive chunks (producer kernel, engine kernel, producer kernel, ...) on the caller's stream, the pool reused

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 17              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 18              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_COMPACTED, ST_SPILLED = 64, 128
 ST_NONFINITE = 32
@@ -25,7 +25,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
            "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
-           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_order_hint"]
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_order_hint", "qmpc_set_debug_balance"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
@@ -116,6 +116,7 @@ def load_library():
         lib.qmpc_set_chunks.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_dense.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_order_hint.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_debug_balance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_block_start.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.qmpc_set_model.argtypes = [C.c_void_p, C.c_int]
@@ -497,6 +498,9 @@ class BatchedConvexMPC:
         """0 / 1: multi-round launches take the robots in blockIdx order / hardest first by the previous call's
         iteration counts (default; include/qmpc.h)."""
         self._check(self.lib.qmpc_set_order_hint(self.h, int(mode)), "qmpc_set_order_hint")
+
+    def set_debug_balance(self, mode):
+        self._check(self.lib.qmpc_set_debug_balance(self.h, int(mode)), "qmpc_set_debug_balance")
 
     def set_chunks(self, n):
         self._check(self.lib.qmpc_set_chunks(self.h, int(n)), "qmpc_set_chunks")

@@ -170,6 +170,7 @@ struct qmpc_ctx {
   int* d_hint_max = nullptr;    // [3] largest iteration count of the last calls (slots rotated by hint_call: read / fold / clear)
   unsigned hint_call = 0;
   int* d_cu_slots = nullptr;
+  int bal_debug = 0;  // qmpc_set_debug_balance
   int max_stance = 0;          // caller's bound on stance foot-steps per robot (0 = unknown)
   int min_stance = 0;          // ... and lower bound (0 = unknown)
   int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
@@ -258,7 +259,7 @@ int ensure_pools(qmpc_ctx* c);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 17; }
+int qmpc_abi_version(void) { return 18; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -495,6 +496,12 @@ int qmpc_set_block_start(qmpc_handle c, int on) {
 int qmpc_set_dense(qmpc_handle c, int mode) {
   if (!c || mode < 0 || mode > 2) return QMPC_ERR_ARG;
   c->dense = mode;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug_balance(qmpc_handle c, int mode) {
+  if (!c || mode < 0 || mode > 2) return QMPC_ERR_ARG;
+  c->bal_debug = mode;
   return QMPC_OK;
 }
 
@@ -745,6 +752,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_clk = c->dbg_clk;
   P.hint_iters = (c->order_hint && !capturing) ? c->d_hint_iters : nullptr;
   P.cu_slots = c->d_cu_slots;
+  P.bal_debug = c->bal_debug;
 
   P.ovpool = c->d_ovpool;
   P.ov_nslice = c->ov_nslice;

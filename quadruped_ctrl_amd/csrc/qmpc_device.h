@@ -191,6 +191,7 @@ struct QmpcParams {
   // heuristic: no atomic); the first workgroup of the call clears *hint_max_z for the next call (three slots, rotated by the host)
   // the 96-row class's wave placement (qmpc_kernels.hip: balance_waves): one int per CU, [xcc 3 bits][se, sh, cu 8 bits]
   int* cu_slots;
+  int bal_debug;  // test hook (qmpc_set_debug_balance): 1 = no slot word (every workgroup keeps its pairs on SIMDs 0 and 1), 2 = treat the placement as irregular (waves 0..5 stay)
   int hint_hard;
   const int32_t* hint_max_r;
   int32_t* hint_max_w;

@@ -3096,7 +3096,7 @@ __device__ __forceinline__ int balance_waves(Smem<RB>& S, const QmpcParams& P) {
     if (threadIdx.x == 0) {
       int bit = 0;
       const int cu = (int)(((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu));
-      if (P.cu_slots) {
+      if (P.cu_slots && P.bal_debug == 0) {
         if (!(atomicOr(&P.cu_slots[cu], 1) & 1)) bit = 1;
         else if (!(atomicOr(&P.cu_slots[cu], 2) & 2)) bit = 2;
       }
@@ -3120,7 +3120,7 @@ __device__ __forceinline__ int balance_waves(Smem<RB>& S, const QmpcParams& P) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) seen[q] += (sd == q) ? 1 : 0;
     }
-    if (!regular || __builtin_popcount(keep) != 6) keep = 0x3fu;
+    if (!regular || __builtin_popcount(keep) != 6 || P.bal_debug == 2) keep = 0x3fu;
     if (!((keep >> pw) & 1u)) return -1;
     return 64 * __builtin_popcount(keep & ((1u << pw) - 1u)) + lane;
   }

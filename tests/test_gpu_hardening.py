@@ -273,3 +273,25 @@ def test_order_hint_changes_the_order_not_the_results(mpc_factory):
         assert np.array_equal(again["soln"], base["soln"]) and np.array_equal(again["iters"], base["iters"])
         print(f"   order hint: B={B} h={b['horizon']} iters mean {base['iters'].mean():.2f} max {base['iters'].max()}: bit-identical "
               f"(exact / stale / after a call of another size)")
+
+
+def test_wave_placement_of_the_96_row_class_does_not_change_results(mpc_factory):
+    """The 96-row class's solve kernels are launched with eight waves; six stay, picked by where the hardware put them
+    (HW_REG_HW_ID) and by a per-CU slot word so that two co-resident workgroups complement each other.
+    Whichever six stay -- balanced, everybody the same choice, or the fallback 'waves 0..5' -- the logical thread layout is
+    the same: bit-identical results, first of the chain (trot at horizon 16) and as a list consumer (random contact tables),
+    and the slot words are all released when the call is over (the next call finds both bits free again)."""
+    for b, stance in ((W.make_config(3, batch=1300), True), (W.make_config(4, batch=1500), False)):
+        m = mpc_factory(b)
+        if stance:
+            m.set_max_stance(int((b["gait"] != 0).sum(1).max()))
+            m.set_min_stance(int((b["gait"] != 0).sum(1).min()))
+        m.set_order_hint(0)
+        base = m.solve(b, full=True)
+        assert ((base["status"] & 47) == 0).all()
+        for mode in (1, 2, 0, 0):
+            m.set_debug_balance(mode)
+            res = m.solve(b, full=True)
+            for k in ("grf", "soln", "iters"):
+                assert np.array_equal(res[k], base[k]), (mode, k)
+            assert np.array_equal(res["status"], base["status"]), mode
