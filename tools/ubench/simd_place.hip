@@ -44,6 +44,13 @@ int main(int argc, char** argv) {
     nb[key]++;
     pat[mine]++;
   }
+  {  // which SIMD does each wave INDEX land on?  (the engine wave of the solve kernels is wave 0)
+    int hist[8][4] = {};
+    for (int b = 0; b < blocks; ++b)
+      for (int w = 0; w < threads / 64; ++w) hist[w][(h[(b * 8 + w) * 2] >> 4) & 3]++;
+    printf("wave index -> SIMD histogram:\n");
+    for (int w = 0; w < threads / 64; ++w) printf("  wave %d: %d %d %d %d\n", w, hist[w][0], hist[w][1], hist[w][2], hist[w][3]);
+  }
   printf("per-workgroup SIMD patterns (waves on SIMD0..3 -> count):\n");
   for (auto& p : pat) printf("  %d %d %d %d : %d\n", p.first[0], p.first[1], p.first[2], p.first[3], p.second);
   std::map<std::vector<int>, int> cupat;
