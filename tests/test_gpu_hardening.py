@@ -295,3 +295,25 @@ def test_wave_placement_of_the_96_row_class_does_not_change_results(mpc_factory)
             for k in ("grf", "soln", "iters"):
                 assert np.array_equal(res[k], base[k]), (mode, k)
             assert np.array_equal(res["status"], base["status"]), mode
+
+
+def test_order_hint_over_a_closed_loop_rollout(mpc_factory):
+    """What a controller does: the same robots cycle after cycle, every cycle a new contact-table phase and a new state
+    (workloads.Rollout, random pushes), ONE call per cycle on a handle that keeps the previous cycle's iteration counts.
+    A launch of several rounds (1500 robots, mixed gaits) and a one-round launch (700): forces, solutions and iteration counts
+    equal the plain order's bit for bit in every cycle."""
+    for B in (1500, 700):
+        ro = W.Rollout(B, 10, "mixed", seed=11, kick=1.0)
+        b = ro.record()
+        plain, hinted = mpc_factory(b, max_batch=2048), mpc_factory(b, max_batch=2048)
+        plain.set_order_hint(0)
+        worst = 0
+        for cycle in range(6):
+            b = ro.record()
+            p, h = plain.solve(b, full=True), hinted.solve(b, full=True)
+            assert ((p["status"] & 47) == 0).all()
+            for k in ("grf", "soln", "iters"):
+                assert np.array_equal(p[k], h[k]), (B, cycle, k)
+            worst = max(worst, int(p["iters"].max()))
+            ro.advance(p["grf"])
+        print(f"   rollout B={B}: 6 cycles, iterations up to {worst}: hinted == plain in every cycle")
