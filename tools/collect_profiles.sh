@@ -9,6 +9,9 @@ for n in cfg1 standing_h10 standing_h14 standing_h16 trot_h16; do
   cp gpurun_out/$T/kernel_stats_$n.csv profiles/${T}_kernel_stats_$n.csv
   cp gpurun_out/$T/pmc_summary_$n.json profiles/${T}_pmc_summary_$n.json
 done
+for n in cfg2 cfg4; do   # (round 4: counters and kernel stats for configs[2] / [4] as well)
+  for f in bench_$n.json kernel_stats_$n.csv pmc_summary_$n.json; do [ -f gpurun_out/$T/$f ] && cp gpurun_out/$T/$f profiles/${T}_$f; done
+done
 cp gpurun_out/$T/shim_latency.json profiles/${T}_shim_latency.json
 cp gpurun_out/$T/warm_rollout.json profiles/${T}_warm_rollout.json
 cp gpurun_out/$T/class_stats.txt profiles/${T}_class_stats.txt 2>/dev/null || true
@@ -45,7 +48,7 @@ for pair in "cfg1 config1 1024" "standing_h10 standing_h10 1024" "standing_h14 s
   set -- $pair
   python tools/pmc_to_latest.py profiles/${T}_pmc_summary_$1.json $2 $3 profiles/${T}_pmc_summary_$1.json profiles/${T}_kernel_stats_$1.csv > /dev/null
 done
-for pair in "large_stand_h36 long-stand_h36 1024" "large_trot_h36 long-trot_h36 1024"; do
+for pair in "large_stand_h36 long-stand_h36 1024" "large_trot_h36 long-trot_h36 1024" "cfg2 config2 4096" "cfg4 config4 8192"; do
   set -- $pair
   [ -f profiles/${T}_pmc_summary_$1.json ] && python tools/pmc_to_latest.py profiles/${T}_pmc_summary_$1.json $2 $3 profiles/${T}_pmc_summary_$1.json profiles/${T}_kernel_stats_$1.csv > /dev/null
 done

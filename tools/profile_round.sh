@@ -25,6 +25,8 @@ run standing_h10 --workload standing --horizon 10
 run standing_h14 --workload standing --horizon 14
 run standing_h16 --workload standing --horizon 16
 run trot_h16 --config 3
+run cfg2 --config 2
+run cfg4 --config 4
 # long horizons (the 192-row class + the decoupled engine): trot at 24 segments, bounding-type gait at 36
 python $R/bench.py --steps 100 --workload long-trot --horizon 24 --no-cpu-all-cores > $OUT/bench_long_trot_h24.json 2> $OUT/bench_long_trot_h24.err
 python $R/bench.py --steps 50 --workload long-bound --horizon 36 --no-cpu-all-cores > $OUT/bench_long_bound_h36.json 2> $OUT/bench_long_bound_h36.err
@@ -56,7 +58,7 @@ python $R/tools/engine_phase.py s14 1024 2>/dev/null | grep -v amdgpu >> $OUT/en
 QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s10 1024 2>/dev/null | grep -v amdgpu | head -7 > $OUT/sweep_phases.txt
 QMPC_PHASE_SWEEP_ONLY=1 python $R/tools/gpu_phases.py s14 1024 2>/dev/null | grep -v amdgpu | head -7 >> $OUT/sweep_phases.txt
 # bench lines only for the remaining BASELINE configs (one GPU's shard), batch scaling, calm standing, caller-side pipeline
-for c in 0 2 4; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
+for c in 0; do python $R/bench.py --steps 200 --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2>/dev/null; done
 for a in "--config 4 --batch 8192" "--workload standing --horizon 10 --batch 1024" "--workload standing --horizon 16 --batch 1024"; do python $R/tools/class_stats.py $a; done > $OUT/class_stats.txt 2>/dev/null
 for b in 256 4096 16384 65536; do python $R/bench.py --steps 100 --batch $b --no-cpu-baseline --no-pipelined > $OUT/bench_cfg1_b$b.json 2>/dev/null; done
 python $R/bench.py --steps 100 --caller-side fused --no-cpu-baseline > $OUT/bench_caller_fused.json 2>/dev/null

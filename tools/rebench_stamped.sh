@@ -5,4 +5,6 @@ run standing_h10 --workload standing --horizon 10
 run standing_h14 --workload standing --horizon 14
 run standing_h16 --workload standing --horizon 16
 run trot_h16 --config 3
+run cfg2 --config 2
+run cfg4 --config 4
 ls -la $OUT
