@@ -303,6 +303,16 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
     e = hipMalloc(&c->d_ovpool, sizeof(double) * (size_t)c->ov_nslice * QMPC_OV_SLICE);
   }
   if (e == hipSuccess) e = qmpc_prepare();
+  if (e == hipSuccess) {
+    // the runtime loads a translation unit's code object at the first launch of one of its kernels (2 MiB of device
+    // memory): this file's small kernels (fill, order hint) are first launched HERE, not inside some later solve call
+    e = fill_ints(c->d_hint_max, 4, 0, nullptr);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(qmpc_order_kernel, dim3(1), dim3(1024), 0, nullptr, (const int*)c->d_hint_iters, c->d_order, 1);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  }
   if (e != hipSuccess) {
     qmpc_destroy(c);
     return QMPC_ERR_DEVICE;
