@@ -931,7 +931,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     // the launch ends with whichever hard robot started last), takes the robots in the order of their iteration counts in the
     // previous call -- the same robots one MPC cycle earlier -- longest first.  Results do not depend on the order.
     // A launch of ONE round (the order cannot matter) uses the counts differently: the robots the previous call found hard
-    // keep the highest issue priority through their sweep (qmpc_device.h: hint_hard) -- batch 1024, trot: 2.42e7 -> 2.60e7 QP/s.
+    // keep the highest issue priority through their sweep (qmpc_device.h: hint_hard) -- batch 1024, trot: 2.42e7 -> 2.75e7 QP/s.
     // (Only there: in a launch of many rounds it costs 3 %, measured at 16384 robots.)
     P.order = nullptr;
     P.hint_hard = 0;
