@@ -317,3 +317,23 @@ def test_order_hint_over_a_closed_loop_rollout(mpc_factory):
             worst = max(worst, int(p["iters"].max()))
             ro.advance(p["grf"])
         print(f"   rollout B={B}: 6 cycles, iterations up to {worst}: hinted == plain in every cycle")
+
+
+def test_order_hint_random_call_sequences(mpc_factory):
+    """A handle used the way a test bench would abuse it: calls of changing batch sizes (one round, several rounds), two
+    different robot fleets taking turns in the same rows, chains with and without larger classes.  Whatever the hint state
+    left by the call before, every call's results equal those of a handle without the hint."""
+    rng = np.random.default_rng(5)
+    fleets = [W.make_config(2, batch=3000), W.make_config(4, batch=3000)]
+    plain, hinted = mpc_factory(fleets[0]), mpc_factory(fleets[0])
+    plain.set_order_hint(0)
+    for call in range(14):
+        f = fleets[int(rng.integers(0, 2))]
+        B = int(rng.choice([3000, 3000, 1700, 900, 900, 257]))
+        sub = {k: (v[:B].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (3000,) else v) for k, v in f.items()}
+        sub["batch"] = B
+        p, h = plain.solve(sub, full=True), hinted.solve(sub, full=True)
+        assert ((p["status"] & 47) == 0).all()
+        for k in ("grf", "soln", "iters"):
+            assert np.array_equal(p[k], h[k]), (call, B, k)
+        assert np.array_equal(p["status"] & 47, h["status"] & 47)
