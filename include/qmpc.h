@@ -229,7 +229,10 @@ int qmpc_set_dense(qmpc_handle h, int mode);
  * of those counts, longest first (one counting-sort kernel of a few microseconds in front of the call); a launch of ONE round
  * (everybody starts at once) uses them as issue priority instead: the few robots the previous call found hardest keep the
  * highest priority through their Gauss-Jordan sweep, so the launch no longer waits for them.  Scheduling only:
- * a robot's result does not depend on its place (bit-identical, tested); a stale or meaningless hint -- other robots in
+ * a robot's result does not depend on its place (bit-identical, tested -- with the one exception every launch has: when more
+ * robots of a call outgrow their on-chip event pool than the handle has overflow slices, 2048, WHICH of them take the
+ * Schur-form fallback (QMPC_ST_FALLBACK) depends on the order they ran in, and those differ in the last bits, ~1e-15;
+ * seen at 65 536 mixed-gait robots on one GPU); a stale or meaningless hint -- other robots in
  * the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
  * and the JCQP alternate do not use it. */
 int qmpc_set_order_hint(qmpc_handle h, int mode);
