@@ -484,7 +484,7 @@ int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
 
 int qmpc_set_debug_overflow_slices(qmpc_handle c, int n) {
   if (!c) return QMPC_ERR_ARG;
-  const int all = c->max_batch < 1024 ? c->max_batch : 1024;  // what qmpc_create allocated
+  const int all = c->max_batch < 2048 ? c->max_batch : 2048;  // what qmpc_create allocated
   if (n > all) return QMPC_ERR_ARG;  // more slices than allocated
   c->ov_nslice = n < 0 ? all : n;
   return QMPC_OK;
