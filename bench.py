@@ -187,6 +187,8 @@ def main():
                          "hard the highest issue priority), 'off' = robot = workgroup index.  The bench solves the SAME inputs every "
                          "step, so the hint is exact here; the line carries the plain-order rate measured in the same run beside it, "
                          "and profiles/*order_hint* the closed-loop rollouts where the hint is the previous MPC cycle's")
+    ap.add_argument("--no-plain-order", action="store_true",
+                    help="skip the extra plain-order regions (profiling runs: every launch of the trace is then a hinted one)")
     ap.add_argument("--no-hint", action="store_true",
                     help="do not tell the solver the workload's max stance foot-steps (launch every size class)")
     args = ap.parse_args()
@@ -348,7 +350,7 @@ def main():
 
     # ---- extra: the same K steps without the order hint (robot = workgroup index), three regions, the median one
     plain_order = None
-    if world == 1 and args.order_hint == "auto" and not args.caller_side:
+    if world == 1 and args.order_hint == "auto" and not args.caller_side and not args.no_plain_order:
         mpc.set_order_hint(0)
         for _ in range(max(args.warmup, 2)):
             one_step()
