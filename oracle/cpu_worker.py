@@ -1,10 +1,10 @@
 """One worker of the all-cores CPU baseline -- TEST / BENCH INFRASTRUCTURE ONLY.
 
-    python -m oracle.cpu_worker <workload-json> <seconds>
+    python -m oracle.cpu_worker <workload-json> <seconds> [cpu]
 
 Runs the reference-style pipeline (C restatement of the SolverMPC.cpp assembly + the
 reference's own qpOASES, oracle/_ref) over its robots in a loop for about <seconds> seconds of
-wall time and prints {"solved": n, "elapsed": s}.  bench.py starts one of these per host core
+wall time and prints {"solved": n, "elapsed": s}.  bench.py starts one of these per PHYSICAL host core, pinned to it ([cpu])
 (the reference itself is single-threaded and non-reentrant: file-scope globals,
 convexMPC_interface.cpp:13-20; one process per core is how a user would scale it).
 """
@@ -30,6 +30,12 @@ def make_workload(spec):
 def main():
     spec = json.loads(sys.argv[1])
     seconds = float(sys.argv[2])
+    if len(sys.argv) > 3:
+        try:
+            import os
+            os.sched_setaffinity(0, {int(sys.argv[3])})
+        except (AttributeError, OSError, ValueError):
+            pass
     from oracle import oracle as O
     b = make_workload(spec)
     arr = O.pack_updates(b)

@@ -86,8 +86,18 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
-        # (development only: QMPC_LIB names a variant build of the same library -- tools/build_variant.sh; unset in production)
-        LIB_PATH = os.environ.get("QMPC_LIB") or globals()["LIB_PATH"]
+        # Development only: QMPC_LIB names a VARIANT BUILD of this library made by tools/build_variant.sh.  It is honoured only
+        # for a file inside this checkout's own (git-ignored) variants/ directory -- the environment cannot point a production
+        # load at an arbitrary shared object -- and anything else is refused loudly
+        LIB_PATH = globals()["LIB_PATH"]
+        override = os.environ.get("QMPC_LIB")
+        if override:
+            vdir = os.path.realpath(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "variants"))
+            real = os.path.realpath(override)
+            if os.path.commonpath([real, vdir]) != vdir or os.path.basename(real) != "libqmpc.so":
+                raise RuntimeError(f"QMPC_LIB={override!r} refused: only <checkout>/variants/<name>/libqmpc.so "
+                                   "(tools/build_variant.sh) may replace the in-tree library")
+            LIB_PATH = real
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP extension first "

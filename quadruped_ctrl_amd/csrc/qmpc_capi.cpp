@@ -465,7 +465,7 @@ int qmpc_settings_jcqp(qmpc_handle c, int use_jcqp, int max_iter, double rho, do
     c->admm_alpha = solver_alpha;
     c->admm_term = terminate;
   }
-  return QMPC_OK;
+  return ensure_pools(c);  // (the alternate's launch plan can reach the large-problem pool where the exact solve's does not)
 }
 
 int qmpc_set_warm_start(qmpc_handle c, int32_t* ws_dev, int shift_steps) {
@@ -558,7 +558,7 @@ int qmpc_debug_ld(qmpc_handle) { return QMPC_DBG_LD; }
 // test hook: a work item of the decoupled path after a solve -- which: 0 = 128-row class, 1 = 192-row class, 2 = large
 // problems; hinv_host: ld x ld doubles (ld = 128 / 192 / 448), xu_host: ld doubles, hdr4: {rid, n, nst, status0}
 int qmpc_debug_read_item(qmpc_handle c, int which, int item, double* hinv_host, double* xu_host, int* hdr4) {
-  if (!c || which < 0 || which > 2 || !c->d_wk_hinv[which] || item < 0 || item >= c->wk_cap[which]) return QMPC_ERR_ARG;
+  if (!c || which < 0 || which > 2 || c->wk_cap[which] <= 0 || item < 0 || item >= c->wk_cap[which]) return QMPC_ERR_ARG;
   DeviceGuard g(c->device);
   const size_t ld = which == 0 ? 128 : (which == 1 ? 192 : QMPC_BIG_LD);
   HIP_TRY(c, hipDeviceSynchronize());
@@ -650,21 +650,32 @@ ClassPlan plan_classes(const qmpc_ctx* c, int admm_mode, bool warm) {
 
 // one pool of work items: sk 0 = 128-row class, 1 = 192-row class, 2 = large problems (448-row items)
 int ensure_items(qmpc_ctx* c, int sk) {
-  if (c->d_wk_hinv[sk]) return QMPC_OK;
+  if (c->wk_cap[sk] > 0) return QMPC_OK;  // (set last: a pool counts as present only when ALL its arrays are)
   static const int lim[3] = {QMPC_ITEMS_C2, QMPC_ITEMS_C3, QMPC_ITEMS_BIG};
   const int rb = sk == 0 ? 2 : (sk == 1 ? 3 : 5);
   const size_t ld = sk == 0 ? 128 : (sk == 1 ? 192 : QMPC_BIG_LD);
   const size_t cap = (size_t)(c->max_batch < lim[sk] ? c->max_batch : lim[sk]);
-  HIP_TRY(c, hipMalloc(&c->d_wk_hinv[sk], sizeof(double) * cap * ld * ld));
-  HIP_TRY(c, hipMalloc(&c->d_wk_xu[sk], sizeof(double) * cap * ld));
-  HIP_TRY(c, hipMalloc(&c->d_wk_hdr[sk], sizeof(QmpcWorkHdr) * cap));
-  HIP_TRY(c, hipMalloc(&c->d_wk_order[sk], sizeof(int) * QMPC_ORDER_BUCKETS * cap));
-  {
-    // (the engine grid never exceeds the resident workgroups: slice = blockIdx.x)
-    size_t wgs = (size_t)qmpc_engine_resident(rb);
-    if (wgs == 0 || wgs > cap) wgs = cap;
-    const size_t ev = sk == 0 ? 128 + 64 : (sk == 1 ? 192 + 128 : QMPC_BIG_LD + 192);
-    HIP_TRY(c, hipMalloc(&c->d_wk_ovf[sk], sizeof(double) * wgs * QMPC_ENGINE_OVF_EVENTS * ev));
+  // (the engine grid never exceeds the resident workgroups: slice = blockIdx.x)
+  size_t wgs = (size_t)qmpc_engine_resident(rb);
+  if (wgs == 0 || wgs > cap) wgs = cap;
+  const size_t ev = sk == 0 ? 128 + 64 : (sk == 1 ? 192 + 128 : QMPC_BIG_LD + 192);
+  // all or nothing: an allocation that fails half-way (the pools are up to 1.5 GiB) must not leave a pool that LOOKS
+  // present -- the next solve would divide by wk_cap == 0 or launch on null arrays
+  hipError_t e = hipMalloc(&c->d_wk_hinv[sk], sizeof(double) * cap * ld * ld);
+  if (e == hipSuccess) e = hipMalloc(&c->d_wk_xu[sk], sizeof(double) * cap * ld);
+  if (e == hipSuccess) e = hipMalloc(&c->d_wk_hdr[sk], sizeof(QmpcWorkHdr) * cap);
+  if (e == hipSuccess) e = hipMalloc(&c->d_wk_order[sk], sizeof(int) * QMPC_ORDER_BUCKETS * cap);
+  if (e == hipSuccess) e = hipMalloc(&c->d_wk_ovf[sk], sizeof(double) * wgs * QMPC_ENGINE_OVF_EVENTS * ev);
+  if (e != hipSuccess) {
+    if (c->d_wk_hinv[sk]) hipFree(c->d_wk_hinv[sk]);
+    if (c->d_wk_xu[sk]) hipFree(c->d_wk_xu[sk]);
+    if (c->d_wk_hdr[sk]) hipFree(c->d_wk_hdr[sk]);
+    if (c->d_wk_order[sk]) hipFree(c->d_wk_order[sk]);
+    if (c->d_wk_ovf[sk]) hipFree(c->d_wk_ovf[sk]);
+    c->d_wk_hinv[sk] = nullptr; c->d_wk_xu[sk] = nullptr; c->d_wk_hdr[sk] = nullptr;
+    c->d_wk_order[sk] = nullptr; c->d_wk_ovf[sk] = nullptr;
+    (void)hipGetLastError();
+    return fail(c, e, "work-item pool allocation");
   }
   c->wk_cap[sk] = (int)cap;
   return QMPC_OK;
@@ -676,12 +687,17 @@ int ensure_items(qmpc_ctx* c, int sk) {
 int ensure_pools(qmpc_ctx* c) {
   if (!c->is_setup) return QMPC_OK;
   DeviceGuard g(c->device);
-  const ClassPlan pl = plan_classes(c, 0, false);
-  for (int k = pl.k0; k < pl.k1; ++k)
-    if (pl.split[k])
-      if (const int rc = ensure_items(c, kChain[k] == 2 ? 0 : 1)) return rc;
-  if (pl.long_h)
-    if (const int rc = ensure_items(c, 2)) return rc;
+  // the UNION of the plans a solve on this handle can make: the exact solve, and -- when the JCQP alternate is selected --
+  // its own plan (use_jcqp = 1 makes every robot of a long horizon a large problem whatever the stance hint says)
+  const int modes[2] = {0, c->admm_mode};
+  for (int m = 0; m < (c->admm_mode ? 2 : 1); ++m) {
+    const ClassPlan pl = plan_classes(c, modes[m], false);
+    for (int k = pl.k0; k < pl.k1; ++k)
+      if (pl.split[k])
+        if (const int rc = ensure_items(c, kChain[k] == 2 ? 0 : 1)) return rc;
+    if (pl.long_h)
+      if (const int rc = ensure_items(c, 2)) return rc;
+  }
   return QMPC_OK;
 }
 
@@ -776,11 +792,11 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   // launching would leave the following call on counters nobody cleared
   const ClassPlan pl = plan_classes(c, P.admm_mode, P.ws != nullptr);
   for (int k = pl.k0; k < pl.k1; ++k)
-    if (pl.split[k] && !c->d_wk_hinv[kChain[k] == 2 ? 0 : 1]) {
+    if (pl.split[k] && c->wk_cap[kChain[k] == 2 ? 0 : 1] <= 0) {
       c->err = "work-item pool missing (qmpc_setup / qmpc_reserve allocate it)";
       return QMPC_ERR_STATE;
     }
-  if (pl.long_h && !c->d_wk_hinv[2]) {
+  if (pl.long_h && c->wk_cap[2] <= 0) {
     c->err = "large-problem pool missing (qmpc_setup / qmpc_reserve allocate it)";
     return QMPC_ERR_STATE;
   }

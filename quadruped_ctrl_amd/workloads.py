@@ -366,6 +366,93 @@ class Rollout:
         self._place(before & ~after)          # feet that just lifted off: re-placed under the hips
 
 
+class ConfigRollout:
+    """Closed-loop continuation of a BASELINE config (bench.py's `closed_loop` leg): cycle 0 IS the config's
+    record, bit for bit; every later MPC cycle the contact table advances by one step (ConvexMPCLocomotion.cpp:498-590 solves
+    once per 13 ticks with the table of `iteration + 1`, Gait.cpp:187-193 -- for a periodic gait of h segments that is the table
+    rolled by one row; a random contact table of configs[4] is shifted and gets a fresh Bernoulli(0.5) last row), the
+    single-rigid-body state is integrated over dtMPC with the first-step forces the solver returned (the model of
+    SolverMPC.cpp:235-254, explicit Euler, fp64 on the host), SURVEY 8d's state noise is re-injected as pushes, stance feet
+    stay where they are, feet that lift off are re-placed under their hips, and the reference trajectory is rebuilt from the
+    new state by SURVEY 8d's own rule.  Host-side scaffolding: it only PRODUCES input records, all solving is the GPU's."""
+
+    def __init__(self, b, seed=0, kick=1.0, periodic=True):
+        self.b0 = b
+        self.B, self.h = int(b["batch"]), int(b["horizon"])
+        self.rng = np.random.default_rng(SEED0 + 7000 + seed)
+        self.kick, self.periodic = kick, periodic
+        self.cycle = 0
+        f64 = np.float64
+        self.p, self.v, self.w = b["p"].astype(f64), b["v"].astype(f64), b["w"].astype(f64)
+        q = b["q"].astype(f64)
+        qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        self.rpy = np.stack([np.arctan2(2 * (qy * qz + qw * qx), qw * qw - qx * qx - qy * qy + qz * qz),
+                             np.arcsin(np.clip(-2 * (qx * qz - qw * qy), -1, 1)),
+                             np.arctan2(2 * (qx * qy + qw * qz), qw * qw + qx * qx - qy * qy - qz * qz)], 1)
+        self.feet = self.p[:, None, :] + b["r"].astype(f64).reshape(self.B, 3, 4).transpose(0, 2, 1)
+        self.hip = (self.feet - self.p[:, None, :]).copy()       # a lifted foot goes back to where it stood at cycle 0 (body frame, yaw-rotated)
+        self.yaw0 = self.rpy[:, 2].copy()
+        self.table = b["gait"].reshape(self.B, self.h, 4).copy()
+        self.vx_des = b["traj"].reshape(self.B, self.h, 12)[:, 0, 9].astype(f64)
+        self.z_des = b["traj"].reshape(self.B, self.h, 12)[:, 0, 5].astype(f64)
+
+    def record(self):
+        if self.cycle == 0:
+            return self.b0
+        B, h = self.B, self.h
+        f32 = np.float32
+        traj = np.zeros((B, h, 12))
+        k = np.arange(h)[None]
+        traj[:, :, 2] = self.rpy[:, 2:3]                                     # SURVEY 8d: [0, 0, yaw, p_x + v_x dt i, p_y, z_des, 0, 0, 0, vx_des, 0, 0]
+        traj[:, :, 3] = self.p[:, 0:1] + self.v[:, 0:1] * DT_MPC * k
+        traj[:, :, 4] = self.p[:, 1:2]
+        traj[:, :, 5] = self.z_des[:, None]
+        traj[:, :, 9] = self.vx_des[:, None]
+        r = (self.feet - self.p[:, None, :]).transpose(0, 2, 1).reshape(B, 12)
+        d = dict(p=self.p.astype(f32), v=self.v.astype(f32), q=_quat_from_rpy(self.rpy).astype(f32), w=self.w.astype(f32),
+                 r=r.astype(f32), yaw=self.rpy[:, 2].astype(f32), traj=traj.reshape(B, 12 * h).astype(f32))
+        out = _finish(d, B, h, self.table.reshape(B, 4 * h))
+        for key in ("dt", "mu", "f_max", "weights", "alpha", "x_drag"):
+            out[key] = self.b0[key]
+        return out
+
+    def advance(self, grf):
+        f = np.asarray(grf, np.float64).reshape(self.B, 4, 3)
+        m, ib = 9.0, np.array([.07, .26, .242])
+        cy, sy = np.cos(self.rpy[:, 2]), np.sin(self.rpy[:, 2])
+        R = np.zeros((self.B, 3, 3))
+        R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = cy, -sy, sy, cy, 1.0
+        Iinv = np.einsum("bij,j,bkj->bik", R, 1.0 / ib, R)
+        tau = np.cross(self.feet - self.p[:, None, :], f).sum(1)
+        acc = f.sum(1) / m + np.array([0, 0, -9.8])
+        self.p = self.p + self.v * DT_MPC
+        self.v = self.v + acc * DT_MPC
+        self.rpy = self.rpy + np.einsum("bji,bj->bi", R, self.w) * DT_MPC
+        self.w = self.w + np.einsum("bij,bj->bi", Iinv, tau) * DT_MPC
+        if self.kick:
+            self.v += self.rng.normal(0, 0.06 * self.kick, (self.B, 3))
+            self.w += self.rng.normal(0, 0.15 * self.kick, (self.B, 3))
+        before = self.table[:, 0, :] != 0
+        if self.periodic:
+            self.table = np.roll(self.table, -1, axis=1)
+        else:
+            new = (self.rng.random((self.B, 4)) < 0.5).astype(np.uint8)
+            self.table = np.concatenate([self.table[:, 1:], new[:, None, :]], 1)
+            none0 = self.table[:, 0, :].sum(1) == 0
+            self.table[none0, 0, self.rng.integers(0, 4, int(none0.sum()))] = 1
+        after = self.table[:, 0, :] != 0
+        lift = before & ~after
+        dy = self.rpy[:, 2] - self.yaw0
+        c, s_ = np.cos(dy)[:, None], np.sin(dy)[:, None]
+        tgt = self.p[:, None, :] + np.stack([c * self.hip[..., 0] - s_ * self.hip[..., 1], s_ * self.hip[..., 0] + c * self.hip[..., 1],
+                                             self.hip[..., 2]], -1)
+        tgt[..., 2] = self.feet[..., 2]                     # the ground (stairs: the step the foot stood on) does not move with the body
+        tgt[..., 0] += 0.5 * 0.13 * self.v[:, None, 0]
+        tgt[..., 1] += 0.5 * 0.13 * self.v[:, None, 1]
+        self.feet[lift] = tgt[lift]
+        self.cycle += 1
+
+
 def make_kf_stream(batch, steps, seed=5):
     """Synthetic estimator inputs for the Kalman filter (include/qmpc.h qmpc_kf_state): robots moving at a
     constant world velocity with a yawed body, feet planted (so the leg kinematics see the body move

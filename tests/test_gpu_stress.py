@@ -8,7 +8,8 @@ run inside the driver's suite (~1900 robots, about a minute o
 (b) END-TO-END parity against the ORACLE PIPELINE (float restatement of SolverMPC.cpp:296-525 + the reference's
     qpOASES at its own nWSR = 100) for every robot the reference solves under its cap: first-step GRF within
     max(1e-4, 1.5 x spread_i), spread_i = the pairwise spread of the reference's six float evaluation orders on that robot
-    (tests/test_gpu_parity.py::bound_for); flat 1e-4 at horizon 10.  Printed for every family: frac_over_1e-4.
+    (tests/test_gpu_parity.py::bound_for), at every horizon; the spread is evaluated only for robots over the flat 1e-4.
+    Printed for every family: frac_over_1e-4.
 """
 import time
 
@@ -108,7 +109,8 @@ def test_stress_family_solver_and_pipeline_parity(family, mpc_factory):
         ref, nwsr, rc = O.solve_batch(b, idx)
         ok = idx[(rc == 0) & (nwsr < 100)]      # robots the reference solves under its own cap
         pos = np.nonzero((rc == 0) & (nwsr < 100))[0]
-        err, bd = rel_f0(res["grf"][ok], ref[pos]), bound_for(b, ok)
+        err = rel_f0(res["grf"][ok], ref[pos])
+        bd = bound_for(b, ok, err=err)
         report(f"{family} end to end vs the oracle pipeline ({len(ok)} of {len(idx)} under nWSR = 100)", err, bd)
         print(f"   frac_over_1e-4 = {(err > 1e-4).mean():.4f}")
         assert len(ok) >= len(idx) // 4
@@ -173,7 +175,8 @@ def test_stress_large_problems(family, mpc_factory):
     print(f"   oracle pipeline: {int(under.sum())} of {len(order)} robots under the reference's nWSR = 100 cap "
           f"(nWSR {nwsr.tolist()}), {time.time() - t0:.1f} s host")
     if len(ok):
-        err, bd = rel_f0(res["grf"][ok], ref[under]), bound_for(b, ok)
+        err = rel_f0(res["grf"][ok], ref[under])
+        bd = bound_for(b, ok, err=err)
         report(f"{family} end to end vs the oracle pipeline (n_r {3 * nst[ok].min()}..{3 * nst[ok].max()})", err, bd)
         print(f"   frac_over_1e-4 = {(err > 1e-4).mean():.4f}")
         assert (err < bd).all()

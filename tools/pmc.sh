@@ -16,6 +16,6 @@ for grp in \
   "WRITE_SIZE" \
   "GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp -d $OUT/p$i -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --settle 0 --repeats 1 --no-cpu-baseline --no-plain-order "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp -d $OUT/p$i -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --settle 0 --repeats 1 --no-cpu-baseline --no-extras "$@" > $OUT/p$i.log 2>&1
 done
 python $R/tools/pmc_summary.py $OUT

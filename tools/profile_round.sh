@@ -14,7 +14,7 @@ run() {  # name, bench args...
   local name=$1; shift
   python $R/bench.py --steps 300 "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$name -o s --output-format csv -- \
-      python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-pipelined --no-plain-order "$@" > $OUT/stats_$name.log 2>&1
+      python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-pipelined --no-extras "$@" > $OUT/stats_$name.log 2>&1
   find $OUT/stats_$name -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$name.csv \;
   bash $R/tools/pmc.sh $TAG/pmc_$name --no-pipelined "$@" > $OUT/pmc_$name.log 2>&1
   cp $OUT/pmc_$name/pmc_summary.json $OUT/pmc_summary_$name.json 2>/dev/null
