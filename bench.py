@@ -155,6 +155,21 @@ def physical_core_cpus():
         return sorted(allowed)
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time this container may use per period (cgroup v2 cpu.max / v1 cfs quota); None = unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(b, spec, budget_s=8.0, all_cores=True, gpu_grf=None):
     """Reference-style CPU pipeline, bounded sample: one host core in-process, then one worker process per PHYSICAL host
     core (oracle/cpu_worker.py).  gpu_grf: the GPU's first-step forces of the same robots -- the oracle's answers double as
@@ -192,6 +207,12 @@ def cpu_baseline(b, spec, budget_s=8.0, all_cores=True, gpu_grf=None):
             try:
                 logical = os.cpu_count() or 1
                 cpus = physical_core_cpus()
+                # the container may be allowed fewer CPUs than it sees (the GPU boxes: 256 logical CPUs visible, a cgroup quota of
+                # 16): more workers than that are throttled, not parallel -- rounds 1-4 read the collapse as the CPU's
+                quota = cgroup_cpu_quota()
+                if quota is not None and quota >= 1 and int(quota) < len(cpus):
+                    step = len(cpus) // int(quota)
+                    cpus = cpus[::step][:int(quota)]
                 cores = len(cpus)
                 # one pass of a worker's robots ~1 s, so that every worker gets several passes into its window
                 per_solve = dt / (n * reps)
@@ -203,10 +224,11 @@ def cpu_baseline(b, spec, budget_s=8.0, all_cores=True, gpu_grf=None):
                 outs = [json.loads(p.communicate(timeout=180)[0].strip().splitlines()[-1]) for p in procs]
                 total = sum(o["solved"] for o in outs)
                 span = max(o["elapsed"] for o in outs)
-                res["all_cores"] = {"value": total / span, "unit": "QP solves/s", "cores": cores, "physical_cores": cores,
-                                    "logical_cores": logical, "per_core": total / span / cores, "cpu_model": cpu_model(),
-                                    "sample": f"{cores} worker processes, one pinned to each PHYSICAL host core ({logical} logical; the "
-                                              f"reference is single-threaded and non-reentrant), each looping over the first "
+                res["all_cores"] = {"value": total / span, "unit": "QP solves/s", "cores": cores, "physical_cores_visible": len(physical_core_cpus()),
+                                    "logical_cores": logical, "cgroup_cpu_quota": quota, "per_core": total / span / cores, "cpu_model": cpu_model(),
+                                    "sample": f"{cores} worker processes, each pinned to a PHYSICAL host core of its own -- as many as the "
+                                              f"container's cgroup CPU quota allows ({quota}; {logical} logical CPUs visible; the "
+                                              f"reference is single-threaded and non-reentrant) --, each looping over the first "
                                               f"{wspec['batch']} robots for {budget_s:.0f} s"}
             except Exception as e:
                 res["all_cores"] = {"value": None, "error": repr(e)}

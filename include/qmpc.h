@@ -219,7 +219,7 @@ int qmpc_set_block_start(qmpc_handle h, int on);
  * the slots the other four leave (trot: +3.5 % at 2048 robots, +8 % at 4096, +14 % from 8192 on); a single round (1024 robots)
  * is bound by its slowest robot and would lose 1 - 11 %.  mode 1 (default): used by handles created for at least 2048 robots when the 64-row class is the
  * whole chain (qmpc_set_max_stance says every robot fits it) -- the handle's size decides, never a call's -- and, with larger
- * classes behind it in the chain, for calls of up to 8192 robots (their overflow-pool slices: 2048 per handle; configs[4] + 2 %);
+ * classes behind it in the chain as well (configs[4] + 2 %; its robots' overflow-pool slices are recycled within a call);
  * mode 0: never; mode 2: whenever the chain is that class alone.  Same arithmetic: bit-identical results (tested). */
 int qmpc_set_dense(qmpc_handle h, int mode);
 /* Order hint.  A launch of several rounds of workgroups ends with whichever hard robot started last.  A controller solves
@@ -229,11 +229,11 @@ int qmpc_set_dense(qmpc_handle h, int mode);
  * of those counts, longest first (one counting-sort kernel of a few microseconds in front of the call); a launch of ONE round
  * (everybody starts at once) uses them as issue priority instead: the few robots the previous call found hardest keep the
  * highest priority through their Gauss-Jordan sweep, so the launch no longer waits for them.  Scheduling only:
- * a robot's result does not depend on its place (bit-identical, tested -- with the one exception every launch has: when more
- * robots of a call outgrow their on-chip event pool than the handle has overflow slices, 2048, WHICH of them take the
- * Schur-form fallback (QMPC_ST_FALLBACK) depends on the order they ran in, and those differ in the last bits, ~1e-15;
- * seen at 65 536 mixed-gait robots on one GPU); a stale or meaningless hint -- other robots in
- * the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
+ * a robot's result does not depend on its place (bit-identical, tested; until round 4 there was one exception -- more robots of a
+ * call outgrowing their on-chip event pool than the handle had overflow slices, 2048, at 65 536 mixed-gait robots on one GPU:
+ * WHICH of them took the Schur-form fallback depended on the order they ran in -- closed since the slices are recycled within
+ * a call); a stale or meaningless hint -- other robots in
+ the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
  * and the JCQP alternate do not use it. */
 int qmpc_set_order_hint(qmpc_handle h, int mode);
 /* Test hook.  The 96-row class's solve kernels are launched with eight waves of which six stay, chosen so that the two
@@ -269,6 +269,13 @@ int qmpc_reserve(qmpc_handle h);
  * wired into the record entry points). */
 #define QMPC_WS_SLOTS 64
 int qmpc_set_warm_start(qmpc_handle h, int32_t* ws_dev, int shift_steps);
+/* Selective warm start: with min_iters > 0 only the robots that needed at least min_iters active-set
+ * iterations in the handle's previous call (the counts the order hint keeps, qmpc_set_order_hint must be on) read their
+ * previous working set; all others start cold -- a launch waits for its hardest robot, and the easy majority only pays for
+ * wrong guesses.  0 (default): every robot starts warm while a buffer is set.  Same unique minimiser either way.
+ * Measured on closed-loop rollouts (profiles/r05_b_warm_select.txt): NOT faster -- the launch's maximum iteration count
+ * goes UP with a warm start (17 -> 22, 28 -> 38), whoever else starts cold; kept as an option, off by default. */
+int qmpc_set_warm_start_min_iters(qmpc_handle h, int min_iters);
 
 /* Solve `batch` independent MPC problems.  All pointers are DEVICE pointers
  * valid on the handle's device; the call only enqueues work on `stream`
@@ -307,10 +314,15 @@ int qmpc_debug_ld(qmpc_handle h);
  * quat_to_rpy (SolverMPC.cpp:257-267) -- so that a test can separate "same libm bits" from
  * "same algebra" when it compares the assembled QP with an fp64 model.  NULL = off. */
 int qmpc_set_debug_aux(qmpc_handle h, double* aux_dev);
-/* Test hook: use only the first n slices (0 <= n <= min(max_batch, 1024)) of the handle's overflow event pool -- the
- * global-memory records a robot continues on when its on-chip event pool is full (QMPC_ST_SPILLED); robots that find
- * no slice are re-solved by the Schur-form engine (QMPC_ST_FALLBACK).  Negative n restores the default. */
+/* Test hook: use only the first n slices (0 <= n <= min(max_batch, 2048)) of the handle's overflow event pool -- the
+ * global-memory records a robot continues on when its on-chip event pool is full (QMPC_ST_SPILLED).  The slices are
+ * RECYCLED within a call (one flag per slice, released when its robot finishes), so a handle's 2048 slices serve calls of
+ * any size: the need is bounded by the robots in flight; a robot that finds every slice taken waits for one.  With n = 0,
+ * or when the wait times out (qmpc_set_debug_overflow_spin), the robot is re-solved by the Schur-form engine
+ * (QMPC_ST_FALLBACK).  Negative n restores the default. */
 int qmpc_set_debug_overflow_slices(qmpc_handle h, int n);
+/* Test hook: probes a robot makes for a free overflow slice before it gives up (default 2^22; negative restores it). */
+int qmpc_set_debug_overflow_spin(qmpc_handle h, int probes);
 /* Test hook: the decoupled path's engine kernel may hold at most n rank-1 events per robot (0 = its compiled
  * capacity); a robot that needs more is handed back to the one-kernel path (QMPC_ST_FALLBACK). */
 int qmpc_set_debug_engine_events(qmpc_handle h, int n);

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 18              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 19              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_COMPACTED, ST_SPILLED = 64, 128
 ST_NONFINITE = 32
@@ -25,7 +25,8 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
            "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
-           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_order_hint", "qmpc_set_debug_balance"]
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_order_hint", "qmpc_set_debug_balance",
+           "qmpc_set_warm_start_min_iters", "qmpc_set_debug_overflow_spin"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
 
@@ -118,6 +119,7 @@ def load_library():
         lib.qmpc_debug_ld.argtypes = [C.c_void_p]
         lib.qmpc_set_debug_aux.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_debug_overflow_slices.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_debug_overflow_spin.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_debug_pool_busy.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_debug_read_item.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_set_split.argtypes = [C.c_void_p, C.c_int]
@@ -129,6 +131,7 @@ def load_library():
         lib.qmpc_set_debug_balance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_block_start.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_warm_start.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.qmpc_set_warm_start_min_iters.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_model.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_kf_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_kf_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(KfState), C.c_void_p]
@@ -223,6 +226,10 @@ class BatchedConvexMPC:
         self._check(self.lib.qmpc_set_warm_start(self.h, ws.data_ptr(), int(shift_steps)), "qmpc_set_warm_start")
         self._ws = ws
         return ws
+
+    def warm_start_min_iters(self, n):
+        """Selective warm start: only robots with at least n iterations in the previous call start warm (0: all)."""
+        self._check(self.lib.qmpc_set_warm_start_min_iters(self.h, int(n)), "qmpc_set_warm_start_min_iters")
 
     def set_max_stance(self, max_stance_footsteps):
         """Caller's bound on stance foot-steps per robot (0 = unknown)."""
@@ -489,6 +496,10 @@ class BatchedConvexMPC:
     def debug_overflow_slices(self, n):
         """Test hook: use only n slices of the overflow event pool (negative: all)."""
         self._check(self.lib.qmpc_set_debug_overflow_slices(self.h, int(n)), "qmpc_set_debug_overflow_slices")
+
+    def debug_overflow_spin(self, probes):
+        """Test hook: probes for a free overflow slice before a robot falls back (negative: default)."""
+        self._check(self.lib.qmpc_set_debug_overflow_spin(self.h, int(probes)), "qmpc_set_debug_overflow_spin")
 
     def set_split(self, mode):
         """Decoupled sweep / engine kernels for the 128- and 192-row classes: 0 / False off, 1 automatic by batch

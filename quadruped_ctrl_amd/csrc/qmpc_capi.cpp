@@ -176,13 +176,16 @@ struct qmpc_ctx {
   int admm_mode = 0, admm_max_iter = 10000;  // JCQP alternate, see qmpc_settings_jcqp
   double admm_rho = 1e-7, admm_sigma = 1e-8, admm_alpha = 1.5, admm_term = 0.1;
   double* d_evpool = nullptr;  // largest size class: global event pool (allocated on first use)
-  double* d_ovpool = nullptr;  // the other classes: overflow event pool, ov_nslice slices handed out per launch chain
+  double* d_ovpool = nullptr;  // the other classes: overflow event pool, ov_nslice slices, recycled within a call (one flag per slice)
+  int* d_ovflags = nullptr;    // [ov_nslice_alloc] 0 = free
   int ov_nslice = 0;
+  int ov_spin = 1 << 22;       // probes of a robot that finds every slice taken before it gives up (test hook: qmpc_set_debug_overflow_slices)
   int* d_evflags = nullptr;
   int ev_nslot = 0;
   bool dbg_pool_busy = false;  // test hook: every slice of the 192-row class's pool looks taken (qmpc_set_debug_pool_busy)
   int32_t* ws = nullptr;  // warm-start buffer (device), see qmpc_set_warm_start
   int ws_shift = 1;
+  int ws_min_iters = 0;   // qmpc_set_warm_start_min_iters: only robots with at least this many iterations in the previous call start warm
   double* dbg_H = nullptr;
   double* dbg_g = nullptr;
   double* dbg_aux = nullptr;
@@ -259,7 +262,7 @@ int ensure_pools(qmpc_ctx* c);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 18; }
+int qmpc_abi_version(void) { return 19; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -301,6 +304,8 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
     //  classes -- see the launch loop of solve_impl)
     c->ov_nslice = max_batch < 2048 ? max_batch : 2048;
     e = hipMalloc(&c->d_ovpool, sizeof(double) * (size_t)c->ov_nslice * QMPC_OV_SLICE);
+    if (e == hipSuccess) e = hipMalloc(&c->d_ovflags, sizeof(int) * (size_t)c->ov_nslice);
+    if (e == hipSuccess) e = hipMemset(c->d_ovflags, 0, sizeof(int) * (size_t)c->ov_nslice);
   }
   if (e == hipSuccess) e = qmpc_prepare();
   if (e == hipSuccess) {
@@ -331,6 +336,7 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_stage) hipFree(h->d_stage);
     if (h->d_evpool) hipFree(h->d_evpool);
     if (h->d_ovpool) hipFree(h->d_ovpool);
+    if (h->d_ovflags) hipFree(h->d_ovflags);
     if (h->d_evflags) hipFree(h->d_evflags);
     if (h->d_fb_lists) hipFree(h->d_fb_lists);
     if (h->d_hint_iters) hipFree(h->d_hint_iters);
@@ -475,10 +481,22 @@ int qmpc_set_warm_start(qmpc_handle c, int32_t* ws_dev, int shift_steps) {
   return QMPC_OK;
 }
 
+int qmpc_set_warm_start_min_iters(qmpc_handle c, int min_iters) {
+  if (!c || min_iters < 0) return QMPC_ERR_ARG;
+  c->ws_min_iters = min_iters;
+  return QMPC_OK;
+}
+
 int qmpc_set_debug(qmpc_handle c, double* H_dev, double* g_dev) {
   if (!c) return QMPC_ERR_ARG;
   c->dbg_H = H_dev;
   c->dbg_g = g_dev;
+  return QMPC_OK;
+}
+
+int qmpc_set_debug_overflow_spin(qmpc_handle c, int probes) {
+  if (!c) return QMPC_ERR_ARG;
+  c->ov_spin = probes < 0 ? (1 << 22) : probes;
   return QMPC_OK;
 }
 
@@ -764,6 +782,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.tol = c->tol;
   P.ws = c->ws;
   P.ws_shift = c->ws_shift;
+  P.ws_min_iters = c->ws_min_iters;
   if (c->admm_mode && in) {  // (record mode only: the command mode always solves exactly)
     P.admm_mode = c->admm_mode;
     P.admm_max_iter = c->admm_max_iter;
@@ -782,6 +801,8 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
 
   P.ovpool = c->d_ovpool;
   P.ov_nslice = c->ov_nslice;
+  P.ov_flags = c->d_ovflags;
+  P.ov_spin = c->ov_spin;
   P.evpool = c->d_evpool;
   P.evflags = c->d_evflags;
   P.ev_nslot = c->ev_nslot;
@@ -937,11 +958,12 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     // instead of 28 send a thousand of them to the overflow pool (configs[4]: -40 %)
     int kcls = kChain[k];
     // Chains with larger classes behind it (configs[4]: random contact tables): their robots iterate longer, and 16 events
-    // in LDS instead of 28 send about one in eight of them to the overflow pool -- with a slice for each of them (2048 per handle:
-    // calls of up to 8192 robots; results are bit-identical either way, so the CALL's size may decide here) the launch still
-    // gains: configs[4] 492 -> 482 us per 8192 robots (+2 %); with 1024 slices it lost 40 % to the Schur-form fallback
-    if (kcls == 1 && pl.k1 - pl.k0 > 1 && !pl.long_h && c->dense == 1 && c->max_batch >= 2048 && c->ov_nslice >= 2048 && batch <= 4 * c->ov_nslice)
-      kcls = 6;
+    // in LDS instead of 28 send about one in eight of them to the overflow pool; the launch still gains (configs[4] 492 -> 482 us
+    // per 8192 robots, +2 %) as long as every one of them finds a slice there -- which, the slices being RECYCLED within a call
+    // since round 5 (a flag per slice, released when its robot finishes: the need is bounded by the robots in flight), holds for
+    // any batch size.  So this choice, too, is made by the HANDLE's size alone (until round 4 it also looked at the call's:
+    // batch <= 4 x the slices)
+    if (kcls == 1 && pl.k1 - pl.k0 > 1 && !pl.long_h && c->dense == 1 && c->max_batch >= 2048) kcls = 6;
     if (kcls == 1 && pl.k1 - pl.k0 == 1 && !pl.long_h && (c->dense == 2 || (c->dense == 1 && c->max_batch >= 2048))) kcls = 6;
     // order hint: the first class of the chain, launched over more robots than it has resident workgroups (several rounds:
     // the launch ends with whichever hard robot started last), takes the robots in the order of their iteration counts in the

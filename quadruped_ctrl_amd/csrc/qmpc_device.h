@@ -109,10 +109,14 @@ struct QmpcParams {
   int ev_nslot;
   int ev_spin;  // bound of the wait for a slice's previous tenant (a workgroup that times out runs the Schur form)
   // classes 1, 4, 2: overflow pool in global memory for the robot whose LDS event pool is full: ov_nslice slices of
-  // QMPC_OV_SLICE doubles, handed out by the counter *ov_count (one per robot and launch chain; nullptr = none)
+  // QMPC_OV_SLICE doubles, one flag each (ov_flags: 0 = free; taken with a compare-and-swap, released by the robot when it
+  // is done -- RECYCLED within a call, so the need is bounded by the robots in flight); *ov_count only spreads the probe
+  // sequences of concurrent robots; ov_spin bounds the wait of a robot that finds every slice taken
   double* ovpool;
   int* ov_count;
+  int* ov_flags;
   int ov_nslice;
+  int ov_spin;
   // decoupled path: work items [wk_cap] of this size class -- H^-1 (wk_ld x wk_ld doubles, row-major, symmetric),
   // x_u (wk_ld doubles), header; *wk_count = items produced so far (sweep workgroups take the next index),
   // *wk_qhead = queue head of the engine workgroups; fb_list / fb_count: robots the engine hands back to the
@@ -142,6 +146,9 @@ struct QmpcParams {
   // with this cycle's final working set
   int32_t* ws;
   int ws_shift;
+  // selective warm start (qmpc_set_warm_start_min_iters): only robots that needed at least this many iterations in the
+  // handle's previous call (hint_iters) read their previous working set; everybody else starts cold.  <= 0: every robot
+  int ws_min_iters;
   // work lists: robots handed from one size class to the next
   const int* list;   // nullptr: robot = blockIdx.x
   int* count;        // entries in `list`

@@ -2093,7 +2093,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // remains is a genuine Goldfarb-Idnani state (x optimal on W, multipliers >= 0) and the normal
       // iteration takes over.  The answer is the same unique minimiser; only the path is shorter.
       int cand = -1;
-      if (WARM && P.ws && lane < (KS < QMPC_WS_STRIDE ? KS : QMPC_WS_STRIDE)) {
+      // (selective: a robot the previous call found easy starts cold -- a cold dual active set needs ~|W*| iterations
+      //  anyway, and a wrong guess costs two events; wave-uniform scalar load)
+      bool ws_take = WARM && P.ws != nullptr;
+      if (WARM && ws_take && P.ws_min_iters > 0 && P.hint_iters) ws_take = P.hint_iters[rid] >= P.ws_min_iters;
+      if (WARM && ws_take && lane < (KS < QMPC_WS_STRIDE ? KS : QMPC_WS_STRIDE)) {
         const int eg = P.ws[(size_t)rid * QMPC_WS_STRIDE + lane];  // global id 5 * (4 step + foot) + type
         const int kg = (eg >= 0 ? eg / 5 : 0) - 4 * P.ws_shift;
         if (eg >= 0 && kg >= 0 && kg < nfs) {
@@ -2533,14 +2537,31 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       } else {
         retry = run(std::false_type{}, nullptr);
         if (spill && !retry) {
-          // ---- LDS pool full: take a slice of the overflow pool (one per robot and launch, handed out by a
-          // counter that the first kernel of the previous call cleared), move the records there -- add events
-          // from the bottom, drop events from the top, the rest of the group each side is in zeroed -- and go on
-          int slice = 0;
-          if (lane == 0) slice = P.ov_count ? atomicAdd(P.ov_count, 1) : P.ov_nslice;
+          // ---- LDS pool full: take a slice of the overflow pool, move the records there -- add events from the bottom,
+          // drop events from the top, the rest of the group each side is in zeroed -- and go on.  Slices are RECYCLED: a flag
+          // per slice, taken here (compare-and-swap, the probe sequence started at a per-call counter so that concurrent
+          // robots spread out) and released when this robot is done with it, so the need is bounded by the robots in flight
+          // (at most the resident workgroups, fewer than the 2048 slices of a handle), not by the robots of a call: no
+          // Schur-form fallback for want of a slice, whatever the batch size and the launch order.  A robot that finds
+          // every slice taken waits for one (their holders depend on nobody); the wait is bounded (ov_spin probes), and a
+          // robot that times out -- or a handle without slices -- is re-run with the Schur-form engine, loudly
+          int slice = -1;
+          if (lane == 0 && P.ov_flags && P.ov_nslice > 0) {
+            const unsigned start = P.ov_count ? (unsigned)atomicAdd(P.ov_count, 1) : (unsigned)rid;
+            const unsigned ns = (unsigned)P.ov_nslice;
+            unsigned idx = start % ns;
+            for (int probe = 0; probe < P.ov_spin; ++probe) {
+              if (atomicCAS(&P.ov_flags[idx], 0, 1) == 0) {
+                slice = (int)idx;
+                break;
+              }
+              idx = (idx + 1u == ns) ? 0u : idx + 1u;
+              if (idx == start % ns) __builtin_amdgcn_s_sleep(32);  // once round: everything is taken, give the holders time
+            }
+          }
           slice = __builtin_amdgcn_readfirstlane(slice);
-          if (slice >= P.ov_nslice) {
-            retry = true;  // no slice left: the robot is re-run with the Schur-form engine
+          if (slice < 0) {
+            retry = true;  // no slice (none configured / timed out): the robot is re-run with the Schur-form engine
           } else {
             GlobalF64* const gpool = (GlobalF64*)P.ovpool + (size_t)slice * QMPC_OV_SLICE;
             const double* lp_ = Sb.Sinv;
@@ -2556,6 +2577,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             status |= QMPC_DEV_ST_SPILLED;  // informational
             retry = run(std::true_type{}, gpool);
+            // done with the slice (the iterate lives in registers): every store to it reaches memory before the flag falls --
+            // the next tenant may sit on another XCD, whose L2 is not coherent with this one's inside a kernel
+            // (helper waves: their last read of the slice lies before the barrier at which run() received their partial sums)
+            __threadfence();
+            if (lane == 0) atomicExch(&P.ov_flags[slice], 0);
           }
         }
       }

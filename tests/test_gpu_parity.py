@@ -1063,28 +1063,73 @@ def test_event_pool_overflow_continues_in_global_memory(mk, name, mpc_factory):
         assert np.array_equal(again["soln"], res["soln"]) and np.array_equal(again["status"], res["status"])
 
 
-def test_overflow_pool_exhausted_falls_back(mpc_factory):
-    """More robots run out of on-chip pool in one call than the handle has overflow slices (cut to 2 with the
-    test hook): the surplus is re-solved by the Schur-form engine (bit 16), everybody gets the same answer as
-    with all slices, and every call starts with all slices free again."""
+def test_overflow_slices_are_recycled_within_a_call(mpc_factory):
+    """The overflow slices are recycled (round 5): a flag per slice, taken by the robot whose on-chip event pool is full and
+    released when it is done.  With the pool cut to 2 slices (test hook) and many more robots spilling in one call, every one
+    of them still continues on a slice -- waiting for one if need be -- with the SAME BITS as with all slices (same engine,
+    same arithmetic; no Schur-form fallback); with no slice at all, or a wait that times out at once, the surplus is re-solved
+    by the Schur-form engine (bit 16) to the same minimiser; afterwards every slice is free again."""
     b = W.make_standing(1024, 10)
     m = mpc_factory(b)
-    m.set_split(False)   # (one-kernel path: see above)
+    m.set_split(False)   # (one-kernel path: it owns the overflow pool; the decoupled engine keeps its events in registers)
     base = m.solve(b, full=True)
     sp = np.nonzero(base["status"] & 128)[0]
     assert len(sp) >= 4 and not (base["status"] & 16).any() and ((base["status"] & 47) == 0).all()
     m.debug_overflow_slices(2)
     for _ in range(2):
         cut = m.solve(b, full=True)
-        assert ((cut["status"] & 47) == 0).all()
-        assert int(((cut["status"] & 128) != 0).sum()) == 2 and int(((cut["status"] & 16) != 0).sum()) == len(sp) - 2
-        assert set(np.nonzero(cut["status"] & (128 | 16))[0]) == set(sp)
-        scale = np.abs(base["soln"]).max(1).clip(1.0)
-        assert (np.abs(cut["soln"] - base["soln"]).max(1) / scale).max() < 1e-9     # two engines, one minimiser
-        rest = np.setdiff1d(np.arange(1024), sp)
-        assert np.array_equal(cut["soln"][rest], base["soln"][rest])
+        assert np.array_equal(cut["status"], base["status"]) and np.array_equal(cut["soln"], base["soln"])
+        assert np.array_equal(cut["iters"], base["iters"])
+    scale = np.abs(base["soln"]).max(1).clip(1.0)
+    rest = np.setdiff1d(np.arange(1024), sp)
+    # a wait that gives up after 3 probes: some robots get one of the two slices, the others fall back -- loudly
+    m.debug_overflow_spin(3)
+    cut = m.solve(b, full=True)
+    assert ((cut["status"] & 47) == 0).all()
+    fb = (cut["status"] & 16) != 0
+    assert fb.sum() >= 1 and set(np.nonzero(cut["status"] & (128 | 16))[0]) == set(sp)
+    assert (np.abs(cut["soln"] - base["soln"]).max(1) / scale).max() < 1e-9     # two engines, one minimiser
+    assert np.array_equal(cut["soln"][rest], base["soln"][rest])
+    m.debug_overflow_spin(-1)
+    # no slices at all: every robot that needs one is re-solved by the Schur-form engine
+    m.debug_overflow_slices(0)
+    cut = m.solve(b, full=True)
+    assert ((cut["status"] & 47) == 0).all()
+    assert not (cut["status"] & 128).any() and set(np.nonzero(cut["status"] & 16)[0]) == set(sp)
+    assert (np.abs(cut["soln"] - base["soln"]).max(1) / scale).max() < 1e-9
     m.debug_overflow_slices(-1)
-    assert np.array_equal(m.solve(b, full=True)["soln"], base["soln"])
+    again = m.solve(b, full=True)
+    assert np.array_equal(again["soln"], base["soln"]) and np.array_equal(again["status"], base["status"])
+
+
+def test_large_batch_needs_no_fallback_and_is_order_independent():
+    """a single-GPU batch of tens of thousands of mixed-gait robots used to send more robots to
+    the overflow pool than the handle has slices (2048 handed out once per robot and call): the surplus took the Schur-form
+    fallback, and WHICH robots did depended on the launch order (plain vs hinted differed in the last bits).  With recycled
+    slices: 16 384 mixed-gait robots on the five-per-CU instantiation (16 events in LDS: hundreds of robots spill) with the
+    pool cut to 64 slices -- far fewer than the spilling robots, fewer even than the robots in flight -- take NO fallback, and
+    plain order, hinted order and a second hinted call (another order again) are bit-identical."""
+    from quadruped_ctrl_amd.binding import BatchedConvexMPC
+    B = 16384
+    b = W.make_config(2, batch=B)
+    m = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
+    m.set_max_stance(int((b["gait"] != 0).sum(1).max()))
+    m.set_min_stance(int((b["gait"] != 0).sum(1).min()))
+    m.setup(b["dt"], b["horizon"], b["mu"], b["f_max"])
+    m.debug_overflow_slices(64)
+    m.set_order_hint(0)
+    plain = m.solve(b, full=True)
+    nsp = int(((plain["status"] & 128) != 0).sum())
+    print(f"{B} mixed-gait robots, 64 overflow slices: {nsp} robots continued in the overflow pool, "
+          f"{int(((plain['status'] & 16) != 0).sum())} fell back")
+    assert ((plain["status"] & 47) == 0).all() and not (plain["status"] & 16).any()
+    assert nsp > 4 * 64
+    m.set_order_hint(1)
+    for _ in range(3):          # (the first hinted call has no counts yet; the next ones sort by the previous call's)
+        hinted = m.solve(b, full=True)
+        assert np.array_equal(hinted["soln"], plain["soln"]) and np.array_equal(hinted["status"], plain["status"])
+        assert np.array_equal(hinted["iters"], plain["iters"])
+    m.close()
 
 
 @pytest.mark.parametrize("mk,name", [(lambda: W.make_standing(300, 10), "standing h10"), (lambda: W.make_standing(260, 14), "standing h14"),
@@ -1593,6 +1638,39 @@ def test_torch_custom_op(mpc_factory):
     assert np.abs(gl.cpu().numpy() - mpc_factory(lt).solve(lt)["grf"]).max() < 1e-4
     T.max_stance_hint = 0
     T.release_handles()
+
+
+def test_selective_warm_start(mpc_factory):
+    """qmpc_set_warm_start_min_iters: only robots with at least n iterations in the previous call read
+    their previous working set.  Over a closed-loop rollout: every robot reaches the cold minimiser (<= 1e-9); a robot that
+    was BELOW the threshold in the previous cycle takes the cold path inside the warm instantiation -- same bits and same
+    iteration count as the cold kernel --; with a threshold nobody reaches, the whole batch is bit-identical to cold."""
+    B, h = 256, 10
+    ro = W.Rollout(B, h, "mixed", seed=5)
+    b = ro.record()
+    cold, sel, never = mpc_factory(b), mpc_factory(b), mpc_factory(b)
+    sel.warm_start(B, shift_steps=1)
+    sel.warm_start_min_iters(4)
+    never.warm_start(B, shift_steps=1)
+    never.warm_start_min_iters(100000)
+    prev_sel = None
+    n_cold_path = n_warm_path = 0
+    for c in range(8):
+        b = ro.record()
+        rc, rs, rn = cold.solve(b, full=True), sel.solve(b, full=True), never.solve(b, full=True)
+        assert ((rc["status"] & 47) == 0).all() and ((rs["status"] & 47) == 0).all()
+        assert np.array_equal(rn["soln"], rc["soln"]) and np.array_equal(rn["iters"], rc["iters"])
+        err = np.abs(rs["soln"] - rc["soln"]).max(1) / np.maximum(np.abs(rc["soln"]).max(1), 1.0)
+        assert err.max() < 1e-9, (c, err.max())
+        if prev_sel is not None:
+            easy = prev_sel < 4          # the selective handle's own previous counts decide
+            assert np.array_equal(rs["soln"][easy], rc["soln"][easy]) and np.array_equal(rs["iters"][easy], rc["iters"][easy])
+            n_cold_path += int(easy.sum())
+            n_warm_path += int((~easy).sum())
+        prev_sel = rs["iters"].copy()
+        ro.advance(rc["grf"])
+    print(f"selective warm start: {n_warm_path} robot-cycles started warm, {n_cold_path} cold")
+    assert n_warm_path > 0 and n_cold_path > n_warm_path
 
 
 @pytest.mark.parametrize("gait,h", [("trot", 10), ("mixed", 10), ("stand", 10), ("trot", 16)])
