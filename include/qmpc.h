@@ -220,7 +220,13 @@ int qmpc_set_block_start(qmpc_handle h, int on);
  * is bound by its slowest robot and would lose 1 - 11 %.  mode 1 (default): used by handles created for at least 2048 robots when the 64-row class is the
  * whole chain (qmpc_set_max_stance says every robot fits it) -- the handle's size decides, never a call's -- and, with larger
  * classes behind it in the chain as well (configs[4] + 2 %; its robots' overflow-pool slices are recycled within a call);
- * mode 0: never; mode 2: whenever the chain is that class alone.  Same arithmetic: bit-identical results (tested). */
+ * mode 0: never; mode 2: whenever the chain is that class alone.  Same arithmetic: bit-identical results (tested) -- with one
+ * documented corner: the Schur-form FALLBACK engine of this instantiation (reached only when the fast engine runs
+ * out of its 32 working-set slots, or numerically loses definiteness) shares a smaller LDS pool and holds 56 working-set slots at
+ * n_r = 63, 59 at n_r = 60, all 64 up to n_r = 54, where the four-per-CU instantiation holds 64 throughout; a robot that needed
+ * more -- nearly every variable pinned by an active row, i.e. every foot-step at a vertex of its friction pyramid and the force
+ * limit at once -- would read QMPC_ST_WS_FULL here and be solved there.  Which instantiation runs is a property of the HANDLE
+ * (its max_batch and stance hints), never of a call's size (since round 5 also for chains with larger classes behind). */
 int qmpc_set_dense(qmpc_handle h, int mode);
 /* Order hint.  A launch of several rounds of workgroups ends with whichever hard robot started last.  A controller solves
  * the SAME robots every MPC cycle, and a robot that needed many active-set iterations 26 ms ago needs many now: with

@@ -168,3 +168,58 @@ def test_pack_argument_validation_without_gpu():
     cs, rs = binding.Command(), binding.Record()
     assert lib.qmpc_pack(None, 4, C.byref(cs), C.byref(rs), None) == 1
     assert lib.qmpc_forces_to_body(None, 4, None, None, None, None) == 1
+
+
+@pytest.mark.parametrize("cfg,periodic", [(1, True), (2, True), (4, False)])
+def test_config_rollout_continues_a_baseline_config(cfg, periodic):
+    """bench.py's closed-loop leg (workloads.ConfigRollout): cycle 0 IS the BASELINE config's record; every later cycle has the
+    contact table advanced by one step (periodic gaits: rolled -- OffsetDurationGait with iteration + 1, Gait.cpp:142-166,187-193;
+    random tables: shifted, a fresh last row, at least one stance foot at step 0), the same layout and dtypes, finite states."""
+    B = 24
+    b = W.make_config(cfg, batch=B)
+    ro = W.ConfigRollout(b, periodic=periodic)
+    assert ro.record() is b
+    h = b["horizon"]
+    prev = b["gait"].reshape(B, h, 4).copy()
+    for c in range(1, 5):
+        ref, _, rc = O.solve_batch(ro.record())
+        assert (rc == 0).all()
+        ro.advance(ref[:, :12])
+        r = ro.record()
+        for k, v in b.items():
+            if isinstance(v, np.ndarray):
+                assert r[k].shape == v.shape and r[k].dtype == v.dtype, k
+                assert np.isfinite(r[k].astype(np.float64)).all(), k
+        g = r["gait"].reshape(B, h, 4)
+        assert np.array_equal(g[:, 1:-1], prev[:, 2:])                # one MPC step later
+        if periodic:
+            assert np.array_equal(g[:, 0], prev[:, 1]) and np.array_equal(g[:, -1], prev[:, 0])   # gait period = horizon
+        else:
+            assert (g[:, 0] >= prev[:, 1]).all() and (g[:, 0].sum(1) >= 1).all()   # (a foot is put down where step 0 had none)
+        # r = foot - body, axis-major (RobotState.cpp:25-27): stance feet have not moved in the world
+        prev = g.copy()
+    assert abs(float(np.linalg.norm(r["q"], axis=1).mean()) - 1.0) < 1e-5
+
+
+def test_bench_whole_shard_parity_names_the_robots_over_the_flat_bound():
+    """bench.py: parity_sample covers every robot of the shard, counts and names the robots over 1e-4 and compares them with
+    the reference's own float evaluation-order spread (checked here with a stand-in for the GPU forces)."""
+    import bench
+    b = W.make_config(2, batch=96)
+    ref, nw, bad = O.solve_packed(O.pack_updates(b), b)
+    fake = ref[:, :12].astype(np.float32)
+    fake[7] *= np.float32(1.0 + 3e-4)
+    ps = bench.parity_whole_shard(b, fake, first=(ref[:32], nw[:32]))
+    assert ps["robots"] == 96 and ps["whole_shard"] and ps["robots_over_1e-4"] == 1 and ps["worst_robots"][0]["robot"] == 7
+    assert abs(ps["max_rel_grf_err"] - 3e-4) < 2e-5 and ps["spread_checked_on"] == 1
+    assert ps["all_checked_within_1.5x_reference_spread"] is False       # 3e-4 is not the reference's noise on that robot
+    clean = bench.parity_whole_shard(b, ref[:, :12].astype(np.float32))
+    assert clean["robots_over_1e-4"] == 0 and clean["all_checked_within_1.5x_reference_spread"] is True
+
+
+def test_bench_cpu_core_accounting():
+    import bench
+    cpus = bench.physical_core_cpus()
+    assert 1 <= len(cpus) <= (os.cpu_count() or 1) and len(set(cpus)) == len(cpus)
+    q = bench.cgroup_cpu_quota()
+    assert q is None or q > 0
