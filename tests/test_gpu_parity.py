@@ -191,6 +191,27 @@ def test_full_shard_vs_oracle(cfg, mpc_factory):
         assert 1e-4 < err[771] < bd[771]
 
 
+@pytest.mark.parametrize("cfg,B", [(1, 1024), (2, 1024), (4, 1024)])
+def test_closed_loop_cycles_vs_oracle(cfg, B, mpc_factory):
+    """bench.py's closed-loop leg (workloads.ConfigRollout: the BASELINE config continued with the contact table advancing one
+    step per MPC cycle, ConvexMPCLocomotion.cpp:498-590, and the state integrated with the solver's own forces): the records of
+    later cycles are inputs no other test sees (sunk body height, drifted velocities, re-placed feet).  Cycles 0, 3 and 6,
+    EVERY robot against the oracle pipeline, per-robot bound max(1e-4, 1.5 x reference float-order spread); the order hint is on
+    (the library default), so from cycle 1 on the launch order / priorities come from the previous cycle."""
+    b0 = W.make_config(cfg, batch=B)
+    ro = W.ConfigRollout(b0, periodic=(cfg != 4))
+    m = mpc_factory(b0)
+    for c in range(7):
+        b = ro.record()
+        res = m.solve(b, full=True)
+        assert ((res["status"] & 47) == 0).all(), (c, np.unique(res["status"]))
+        if c in (0, 3, 6):
+            err, bd, capped, whole = full_shard_compare(b, res["grf"], res["soln"])
+            report(f"configs[{cfg}] closed loop, cycle {c}, x{B}", err, bd)
+            assert not capped.any() and (err < bd).all() and (whole < 1e-4).all()
+        ro.advance(res["grf"])
+
+
 def _dump_model_compare(m, b, idx):
     """GPU H_red, g_red (fp64) of robots idx vs the fp64 model fed the kernel's own float
     transcendentals -> worst relative differences (H, g)."""

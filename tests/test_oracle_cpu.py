@@ -230,3 +230,31 @@ def test_sparse_formulation_restatement_and_reference_osqp():
         scale = max(np.abs(xq).max(), 1.0)
         assert np.abs(u_tight - xq).max() / scale < 1e-6
         assert 1e-5 < np.abs(x_ref[12 * prob["T"]:] - xq).max() / scale < 0.2
+
+
+def test_primal_dual_active_set_model_reaches_the_qpoases_minimiser():
+    """oracle/pdas_model.py (round 5 study): whole-set changes of the working set instead of one row per iteration.
+    On the reduced QPs of the fp64 Kronecker model it stops at the reference qpOASES' minimiser (<= 1e-10) after a handful of
+    linear solves where qpOASES needs up to an order of magnitude more working-set recalculations.  (The GPU pre-solver built
+    on it was exact and SLOWER -- profiles/r05_d_pdas_presolver_negative.txt -- so this is a record of the statistics, not a
+    test of the product.)"""
+    from oracle import pdas_model as PM
+    for b, cap in ((W.make_config(1, batch=48), 16), (W.make_config(4, batch=32), 32), (W.make_standing(6, 10), 64)):
+        solves, nwsr = [], []
+        for i in range(b["batch"]):
+            q, it, ok, kmax = PM.solve_robot(b, i, kp=cap, max_it=16)
+            H0, g0, A, lb, ub, _ = O.assemble(b, i)
+            ve, _, _, Ar, lr, ur = O.reduce(H0, g0, A, lb, ub)
+            H, g = K.assemble(b, i)
+            _, Hr, gr, _, _, _ = O.reduce(H, g, A, lb, ub)
+            if gr.size == 0:
+                continue
+            xq, y, used, rc, irc = O.qpoases(Hr, gr, Ar, lr, ur, nwsr=3000)
+            assert rc == 0 and irc == 0
+            if ok:
+                assert np.abs(q[~ve] - xq).max() / max(np.abs(xq).max(), 1.0) < 1e-10
+                solves.append(it)
+                nwsr.append(used)
+        assert len(solves) >= 0.9 * b["batch"]
+        print(f"h={b['horizon']} robots {len(solves)}: PDAS solves mean {np.mean(solves):.2f} max {max(solves)}; qpOASES nWSR mean {np.mean(nwsr):.2f} max {max(nwsr)}")
+        assert np.mean(solves) < np.mean(nwsr) + 0.5
