@@ -4,13 +4,16 @@ The reference hands the reduced QP to qpOASES (SolverMPC.cpp:527-557), an active
 one row per iteration; so does the GPU's Goldfarb-Idnani engine, whose launch at batch 1024 waits for the one
 robot with 13 - 15 such iterations.  A primal-dual active-set (PDAS) iteration changes the whole set at once:
 
-    A+ = (A minus the rows whose multiplier came out negative)  union  (every row violated at x),
+    A+ = (A minus the rows whose multiplier came out negative)  union  (the most violated row of every stance foot-step),
     then x, lambda = the minimiser of the QP with the rows of A+ as EQUALITIES (one k x k solve with S = C_A H^-1 C_A^T).
 
 It stops at a KKT point (no row violated, no multiplier negative) -- the unique minimiser, H > 0 -- typically after 2 - 5
-solves where the one-row methods take 2 - 33.  PDAS can cycle; a revisited set (hash) switches to single changes (add the
-most violated row, else drop the most negative multiplier), and whatever does not converge within `max_it` solves, or needs
-more than `kp` rows, is left to the Goldfarb-Idnani engine from scratch (`ok = False`).  This file mirrors the kernel's
+solves where the one-row methods take 2 - 33.  Adding EVERY violated row (the textbook rule, `per_footstep=False`) cycles on
+0.2 - 2 % of the robots -- the five rows of a foot-step fight each other: two faces of a pyramid join, two multipliers turn
+negative, they leave, the faces are violated again --; adding at most ONE row per foot-step and solve (its most violated one)
+has not cycled on any robot of any family tried (tests/test_oracle_cpu.py; a revisited set would still switch to single
+changes, and whatever does not converge within `max_it` solves, or needs more than `kp` rows, is left to the Goldfarb-Idnani
+engine from scratch: `ok = False`).  This file mirrors the kernel's
 data flow (stance slot x 5 row types, type-major slot order, Gaussian elimination without pivoting that skips dependent
 rows) so that the HIP code can be checked against it iteration by iteration; tests/test_oracle_cpu.py pins it against the
 reference's qpOASES.
@@ -31,7 +34,7 @@ def rows_of(nst, mi, fmax):
     return out
 
 
-def solve(Hinv, g, nst, mi, fmax, tol=1e-9, max_it=12, kp=16, trace=None):
+def solve(Hinv, g, nst, mi, fmax, tol=1e-9, max_it=12, kp=16, trace=None, per_footstep=True):
     """-> (x, lam[nst, 5], solves, ok, kmax)."""
     n = 3 * nst
     R = rows_of(nst, mi, np.broadcast_to(np.asarray(fmax, float), (nst,)))
@@ -56,7 +59,14 @@ def solve(Hinv, g, nst, mi, fmax, tol=1e-9, max_it=12, kp=16, trace=None):
         if it == max_it:
             break
         if not single:
-            new = (act & ~neg) | viol
+            add = viol
+            if per_footstep:   # at most one row per foot-step joins: its most violated one
+                add = np.zeros_like(viol)
+                svv = np.where(viol, sv, np.inf)
+                tb = svv.argmin(1)
+                has = np.isfinite(svv.min(1))
+                add[np.arange(nst)[has], tb[has]] = True
+            new = (act & ~neg) | add
             key = new.tobytes()
             single = key in seen
             seen.append(key)
