@@ -34,7 +34,7 @@ def rows_of(nst, mi, fmax):
     return out
 
 
-def solve(Hinv, g, nst, mi, fmax, tol=1e-9, max_it=12, kp=16, trace=None, per_footstep=True):
+def solve(Hinv, g, nst, mi, fmax, tol=1e-9, max_it=12, kp=28, trace=None, per_footstep=True):
     """-> (x, lam[nst, 5], solves, ok, kmax)."""
     n = 3 * nst
     R = rows_of(nst, mi, np.broadcast_to(np.asarray(fmax, float), (nst,)))

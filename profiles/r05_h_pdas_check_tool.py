@@ -80,7 +80,7 @@ def main():
             same = 0
             idx = list(range(0, B, max(1, B // 48)))
             for i in idx:
-                q, it, ok, kmax = PM.solve_robot(b, i, max_it=a.cap, kp=(28 if B >= 2048 else 32))
+                q, it, ok, kmax = PM.solve_robot(b, i, max_it=a.cap, kp=28)
                 same += int(ok == bool(by[i]) and (not ok or it == p["it"][i]))
             row["model_agrees_on"] = f"{same}/{len(idx)}"
         out.append(row)
