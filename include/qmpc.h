@@ -190,44 +190,6 @@ int qmpc_set_max_stance(qmpc_handle h, int max_stance_footsteps);
  * A robot below the bound is still solved correctly.  0 = no hint. */
 int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
 
-/* Decoupled path of the 128- and 192-row size classes (n_r > 96: all four feet down, dense random contact tables).
- * on (default): the robot's condensed Hessian is inverted by a sweep kernel that leaves the inverse in a work item
- * in global memory (128 / 288 KiB per item, of which the lower block triangle is written; a bounded pool allocated by
- * qmpc_setup, see qmpc_set_chunks), and the active set is run by a second kernel,
- * one robot per small workgroup -- the robots with the most rows violated at the unconstrained minimiser first --
- * with the rank-1 events of the method in the register file of helper waves, instead of one workgroup pinning a whole
- * CU for the whole solve.  Same unique minimiser.  A robot whose history outgrows the engine's registers and LDS
- * continues with the excess in an overflow pool in global memory (QMPC_ST_SPILLED, informational; 160 events per engine
- * workgroup); one that outgrows that as well, or the engine's working-set slots, is re-solved by the one-kernel path
- * (QMPC_ST_FALLBACK).  mode 1 (default): used by handles created for at least 384 robots (128-row class) / 128 robots
- * (192-row class) -- smaller batches are latency-bound and the one-kernel path has one launch less on the critical
- * path; it is the handle's max_batch that decides, never the size of a call, so that a robot's result does not depend
- * on the batch it is solved in (the two paths agree to ~1e-14 relative, not bit for bit); mode 2:
- * always; mode 0: the one-kernel path for every class (QMPC_NO_SPLIT=1 in the environment selects that at
- * qmpc_create).  The JCQP alternate and warm-started solves always take the one-kernel path. */
-int qmpc_set_split(qmpc_handle h, int mode);
-/* Block start of the decoupled path's engine -- EXPERIMENTAL, default off.  The rows of the friction pyramids / force
- * limits that are violated at the unconstrained minimiser are, almost without exception, active at the solution; with
- * on != 0 the engine adds such candidate sets (one row per stance foot-step and round, up to four rounds) as forced
- * additions made by all threads of the workgroup with the records in LDS, removes the rows whose multiplier came out
- * negative and hands a valid Goldfarb-Idnani state to the normal iteration.  Same unique minimiser (tested), but as
- * measured on MI355X not faster than the iteration it replaces: ~3.1 k cycles per forced change against
- * ~4.9 k per iteration, and 20 % more changes.  `iters` counts every forced change like an iteration. */
-int qmpc_set_block_start(qmpc_handle h, int on);
-/* The 64-row size class has a second instantiation sized for FIVE workgroups per CU (96 VGPRs, a 16-event pool in LDS
- * instead of 28): a launch of several rounds of workgroups is bound by instruction issue, and a fifth wave per SIMD fills
- * the slots the other four leave (trot: +3.5 % at 2048 robots, +8 % at 4096, +14 % from 8192 on); a single round (1024 robots)
- * is bound by its slowest robot and would lose 1 - 11 %.  mode 1 (default): used by handles created for at least 2048 robots when the 64-row class is the
- * whole chain (qmpc_set_max_stance says every robot fits it) -- the handle's size decides, never a call's -- and, with larger
- * classes behind it in the chain as well (configs[4] + 2 %; its robots' overflow-pool slices are recycled within a call);
- * mode 0: never; mode 2: whenever the chain is that class alone.  Same arithmetic: bit-identical results (tested) -- with one
- * documented corner: the Schur-form FALLBACK engine of this instantiation (reached only when the fast engine runs
- * out of its 32 working-set slots, or numerically loses definiteness) shares a smaller LDS pool and holds 56 working-set slots at
- * n_r = 63, 59 at n_r = 60, all 64 up to n_r = 54, where the four-per-CU instantiation holds 64 throughout; a robot that needed
- * more -- nearly every variable pinned by an active row, i.e. every foot-step at a vertex of its friction pyramid and the force
- * limit at once -- would read QMPC_ST_WS_FULL here and be solved there.  Which instantiation runs is a property of the HANDLE
- * (its max_batch and stance hints), never of a call's size (since round 5 also for chains with larger classes behind). */
-int qmpc_set_dense(qmpc_handle h, int mode);
 /* Order hint.  A launch of several rounds of workgroups ends with whichever hard robot started last.  A controller solves
  * the SAME robots every MPC cycle, and a robot that needed many active-set iterations 26 ms ago needs many now: with
  * mode 1 (default) every one-kernel solve leaves its iteration count in a per-handle array, and a call of the same batch
@@ -242,46 +204,13 @@ int qmpc_set_dense(qmpc_handle h, int mode);
  the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
  * and the JCQP alternate do not use it. */
 int qmpc_set_order_hint(qmpc_handle h, int mode);
-/* Test hook.  The 96-row class's solve kernels are launched with eight waves of which six stay, chosen so that the two
- * workgroups of a CU load its four SIMDs evenly.  mode 1: every workgroup makes the same choice (no per-CU
- * slot word); mode 2: the fallback "waves 0..5 stay"; mode 0 (default): balanced.  Results are bit-identical in all three. */
-int qmpc_set_debug_balance(qmpc_handle h, int mode);
-/* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for
- * the 128-row class / 192-row class / large problems -- whatever max_batch is; a call with more robots than items runs the
- * class as consecutive chunks (producer kernel, engine kernel, producer kernel, ...) on the caller's stream, the pool reused
- * from chunk to chunk.  Results do not depend on the chunking (tested).  qmpc_set_chunks (test hook): at least n chunks
- * (0 / 1 = as few as the pool allows; at most 64). */
-int qmpc_set_chunks(qmpc_handle h, int n);
-/* Every device allocation of a handle happens in qmpc_create, qmpc_setup (what the horizon makes reachable), the stance
- * hints, qmpc_set_split and here -- NEVER inside a solve call: qmpc_solve / qmpc_solve_commands only enqueue kernels on the
- * caller's stream (no memset nodes either: they replay wrongly with ROCm 7.2), so they can be captured into a hipGraph and replayed
- * (tests/test_gpu_parity.py::test_solve_is_graph_capturable).  qmpc_reserve repeats the allocation step for the current
- * setup; it is implied by qmpc_setup and kept for callers of earlier versions. */
-int qmpc_reserve(qmpc_handle h);
 
-/* Warm start across MPC cycles (the reference cold-starts every solve,
- * SolverMPC.cpp:529-541).  ws_dev[max_batch][QMPC_WS_SLOTS] is a DEVICE buffer the caller keeps
- * between cycles, initialised to -1.  While it is set, every solve (a) reads robot b's previous
- * working set from row b -- global constraint ids 5 * (4 * step + foot) + type, type 0..3 = the
- * friction-pyramid rows of f_block (SolverMPC.cpp:366-370), 4 = fz <= f_max; -1 = empty -- slides
- * it by `shift_steps` horizon steps (1 when the contact table advanced by one MPC step since the
- * last solve; entries that fall off the front or land on a swing foot-step are discarded), adds
- * those constraints first without search, drops the ones whose multiplier comes out negative, and
- * continues with the normal dual active-set iteration; (b) writes the final working set back.
- * The result is the same unique minimiser as a cold solve (the QP is strictly convex); only the
- * iteration path is shorter.  Row order must follow the robots (row b belongs to robot b of every
- * call).  NULL switches warm starting off.  Warm-started solves take the one-kernel path in every size class (the
- * decoupled engine of the 128- / 192-row classes starts cold); qmpc_solve_commands always starts cold (warm starting is
- * wired into the record entry points). */
-#define QMPC_WS_SLOTS 64
-int qmpc_set_warm_start(qmpc_handle h, int32_t* ws_dev, int shift_steps);
-/* Selective warm start: with min_iters > 0 only the robots that needed at least min_iters active-set
- * iterations in the handle's previous call (the counts the order hint keeps, qmpc_set_order_hint must be on) read their
- * previous working set; all others start cold -- a launch waits for its hardest robot, and the easy majority only pays for
- * wrong guesses.  0 (default): every robot starts warm while a buffer is set.  Same unique minimiser either way.
- * Measured on closed-loop rollouts (profiles/r05_b_warm_select.txt): NOT faster -- the launch's maximum iteration count
- * goes UP with a warm start (17 -> 22, 28 -> 38), whoever else starts cold; kept as an option, off by default. */
-int qmpc_set_warm_start_min_iters(qmpc_handle h, int min_iters);
+/* Everything else the library exports lives in two companion headers, so that this one is the surface a caller needs:
+ *   include/qmpc_expert.h -- scheduling / memory knobs whose DEFAULT is the measured optimum (qmpc_set_split, qmpc_set_dense,
+ *                            qmpc_set_chunks, qmpc_reserve, qmpc_set_block_start) and the warm start across MPC cycles, which is
+ *                            correct but measured slower than the cold solve (qmpc_set_warm_start, _min_iters);
+ *   include/qmpc_debug.h  -- test and profiling hooks (qmpc_set_debug_*, qmpc_debug_*): used by tests/ and tools/ only.
+ * Same shared library, same ABI version. */
 
 /* Solve `batch` independent MPC problems.  All pointers are DEVICE pointers
  * valid on the handle's device; the call only enqueues work on `stream`
@@ -308,43 +237,6 @@ int qmpc_solve_host(qmpc_handle h, int batch, const qmpc_inputs* in,
  * handles may share a device.  Returns the first error. */
 int qmpc_solve_sharded(const qmpc_handle* handles, int n_handles, int batch,
                        const qmpc_inputs* in, const qmpc_outputs* out);
-
-/* Test hook: when non-NULL, the next qmpc_solve calls also store the
- * assembled reduced QP of every robot (before the solve) into DEVICE
- * buffers H[B][ld*ld], g[B][ld] (doubles, row-major, ld = qmpc_debug_ld();
- * entries beyond n_r are padding).  Pass NULLs to switch off. */
-int qmpc_set_debug(qmpc_handle h, double* H_dev, double* g_dev);
-int qmpc_debug_ld(qmpc_handle h);
-/* Test hook: DEVICE buffer aux[B][8] receiving, per robot, the float transcendentals exactly as
- * the kernel evaluated them -- cos(yaw), sin(yaw) (RobotState.cpp:30-35) and roll, pitch, yaw of
- * quat_to_rpy (SolverMPC.cpp:257-267) -- so that a test can separate "same libm bits" from
- * "same algebra" when it compares the assembled QP with an fp64 model.  NULL = off. */
-int qmpc_set_debug_aux(qmpc_handle h, double* aux_dev);
-/* Test hook: use only the first n slices (0 <= n <= min(max_batch, 2048)) of the handle's overflow event pool -- the
- * global-memory records a robot continues on when its on-chip event pool is full (QMPC_ST_SPILLED).  The slices are
- * RECYCLED within a call (one flag per slice, released when its robot finishes), so a handle's 2048 slices serve calls of
- * any size: the need is bounded by the robots in flight; a robot that finds every slice taken waits for one.  With n = 0,
- * or when the wait times out (qmpc_set_debug_overflow_spin), the robot is re-solved by the Schur-form engine
- * (QMPC_ST_FALLBACK).  Negative n restores the default. */
-int qmpc_set_debug_overflow_slices(qmpc_handle h, int n);
-/* Test hook: probes a robot makes for a free overflow slice before it gives up (default 2^22; negative restores it). */
-int qmpc_set_debug_overflow_spin(qmpc_handle h, int probes);
-/* Test hook: the decoupled path's engine kernel may hold at most n rank-1 events per robot (0 = its compiled
- * capacity); a robot that needs more is handed back to the one-kernel path (QMPC_ST_FALLBACK). */
-int qmpc_set_debug_engine_events(qmpc_handle h, int n);
-/* Test hook: on != 0 makes every slice of the 192-row class's global event pool look taken, so that every
- * workgroup of that class times out waiting for one: its robots must then be solved by the Schur-form engine
- * (QMPC_ST_FALLBACK set, same answer) instead of proceeding on a slice they do not own. */
-int qmpc_set_debug_pool_busy(qmpc_handle h, int on);
-/* Test hook: copies work item `item` of the decoupled path (which: 0 = 128-row class, 1 = 192-row class, 2 = large problems)
- * to the host after a solve: the inverse (ld x ld doubles, ld = 128 / 192 / 448; the 128- / 192-row classes write the lower block
- * triangle only), x_u (ld doubles), {rid, n, nst, status bits} (4 ints).  Any pointer may be NULL. */
-int qmpc_debug_read_item(qmpc_handle h, int which, int item, double* hinv_host, double* xu_host, int* hdr4);
-/* Test hook: the handle's three counter sets (3 x 256 ints: two ping-ponged by eager calls, one for captured calls) -> host. */
-int qmpc_debug_read_counts(qmpc_handle h, int* host768);
-/* Profiling hook: DEVICE buffer clk[B][16] receiving shader-clock stamps at
- * the kernel's phase boundaries (NULL = off). */
-int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);
 
 /* ---------------------------------------------------------------------------
  * Caller side of the solve, batched (SURVEY.md row a12 and the consumer of

@@ -24,6 +24,8 @@ def make_workload(spec):
         return W.make_standing(spec["batch"], spec["horizon"])
     if kind == "trot":
         return W.make_trot(spec["batch"], spec["horizon"])
+    if kind in ("long-trot", "long-bound", "long-stand"):
+        return W.make_long_horizon(spec["batch"], spec["horizon"], kind[5:])
     raise ValueError(kind)
 
 
@@ -38,6 +40,31 @@ def main():
             pass
     from oracle import oracle as O
     b = make_workload(spec)
+    if spec.get("model") == "sparse":
+        # the reference's SPARSE leg: SparseCMPC's QP (restated, built once, not timed) through the reference's own OSQP
+        # 0.5.0 at its eps = 1e-5 (OsqpTriples.cpp:57-142: set-up + solve + clean-up every cycle)
+        from oracle import sparse_model as SM
+        b["mu"] = SM.SPARSE_MU
+        b["weights"] = np.tile(SM.SPARSE_WEIGHTS.astype(np.float32), (b["batch"], 1))
+        qps = []
+        for i in range(min(b["batch"], int(spec.get("sparse_problems", 16)))):
+            pr = SM.from_batch(b, i, weights=b["weights"][i].astype(np.float64), alpha=float(b["alpha"][i]), mu=b["mu"],
+                               f_max=b["f_max"])
+            if len(pr["blocks"]):
+                qps.append(SM.osqp_prepare(pr["P"], pr["q"], pr["A"], pr["l"], pr["u"]))
+        for c in qps:
+            SM.osqp_call(c)
+        solved = 0
+        t0 = time.perf_counter()
+        while True:
+            for c in qps:
+                SM.osqp_call(c)
+            solved += len(qps)
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                break
+        print(json.dumps({"solved": solved, "elapsed": el}))
+        return
     arr = O.pack_updates(b)
     O.solve_packed(arr, b)                      # warm (page in, malloc arenas)
     solved = 0

@@ -124,26 +124,43 @@ def build(p, v, q, w, feet, contacts, traj, dts, weights=SPARSE_WEIGHTS, alpha=S
             "blocks": blocks, "Ad": Ad, "Bd": Bd, "x0": x0, "g": g}
 
 
-def osqp(P, q, A, l, u, eps=1e-5, max_iter=0, polish=False):
-    """The reference's vendored OSQP 0.5.0 (oracle/_ref/libosqp_ref.so), settings of OsqpTriples.cpp:95-103."""
+def _osqp_lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(os.path.join(_HERE, "_ref", "libosqp_ref.so"))
         _lib.osqp_ref_solve.restype = C.c_longlong
+    return _lib
+
+
+def osqp_prepare(P, q, A, l, u):
+    """The QP in the compressed-sparse-column arrays OSQP takes (what SparseCMPC's triplets become, OsqpTriples.cpp:62-93),
+    built once so that osqp_call times the reference's solver alone."""
     Pc = sp.csc_matrix(sp.triu(sp.csc_matrix(P)))
     Ac = sp.csc_matrix(A)
-    n, m = q.size, l.size
-    x = np.zeros(n)
-    it = C.c_longlong(0)
     arr = lambda a, t: np.ascontiguousarray(a, t)
-    Px, Pi, Pp = arr(Pc.data, np.float64), arr(Pc.indices, np.int64), arr(Pc.indptr, np.int64)
-    Ax, Ai, Ap = arr(Ac.data, np.float64), arr(Ac.indices, np.int64), arr(Ac.indptr, np.int64)
-    qq, ll, uu = arr(q, np.float64), arr(l, np.float64), arr(u, np.float64)
+    return {"n": q.size, "m": l.size,
+            "Px": arr(Pc.data, np.float64), "Pi": arr(Pc.indices, np.int64), "Pp": arr(Pc.indptr, np.int64),
+            "Ax": arr(Ac.data, np.float64), "Ai": arr(Ac.indices, np.int64), "Ap": arr(Ac.indptr, np.int64),
+            "q": arr(q, np.float64), "l": arr(l, np.float64), "u": arr(u, np.float64), "x": np.zeros(q.size)}
+
+
+def osqp_call(c, eps=1e-5, max_iter=0, polish=False):
+    """osqp_setup + osqp_solve + osqp_cleanup of the reference's vendored OSQP 0.5.0 on a prepared QP (every MPC cycle of
+    the reference sets the solver up anew, OsqpTriples.cpp:57-142).  -> (x, status, iterations)."""
+    lib = _osqp_lib()
+    it = C.c_longlong(0)
     ptr = lambda a: a.ctypes.data_as(C.c_void_p)
-    st = _lib.osqp_ref_solve(C.c_longlong(n), C.c_longlong(m), C.c_longlong(Px.size), ptr(Px), ptr(Pi), ptr(Pp), ptr(qq),
-                             C.c_longlong(Ax.size), ptr(Ax), ptr(Ai), ptr(Ap), ptr(ll), ptr(uu), C.c_double(eps),
-                             C.c_double(eps), C.c_longlong(max_iter), C.c_int(1 if polish else 0), ptr(x), C.byref(it))
-    return x, int(st), int(it.value)
+    st = lib.osqp_ref_solve(C.c_longlong(c["n"]), C.c_longlong(c["m"]), C.c_longlong(c["Px"].size), ptr(c["Px"]), ptr(c["Pi"]),
+                            ptr(c["Pp"]), ptr(c["q"]), C.c_longlong(c["Ax"].size), ptr(c["Ax"]), ptr(c["Ai"]), ptr(c["Ap"]),
+                            ptr(c["l"]), ptr(c["u"]), C.c_double(eps), C.c_double(eps), C.c_longlong(max_iter),
+                            C.c_int(1 if polish else 0), ptr(c["x"]), C.byref(it))
+    return c["x"], int(st), int(it.value)
+
+
+def osqp(P, q, A, l, u, eps=1e-5, max_iter=0, polish=False):
+    """The reference's vendored OSQP 0.5.0 (oracle/_ref/libosqp_ref.so), settings of OsqpTriples.cpp:95-103."""
+    x, st, it = osqp_call(osqp_prepare(P, q, A, l, u), eps, max_iter, polish)
+    return x.copy(), st, it
 
 
 def first_step_forces(x, prob):

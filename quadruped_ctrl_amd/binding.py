@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libqmpc.so")
 
 QMPC_OK = 0
-ABI_VERSION = 19              # qmpc_abi_version() this binding was written against
+ABI_VERSION = 20              # qmpc_abi_version() this binding was written against
 ST_MAXITER, ST_NOT_PD, ST_INFEASIBLE, ST_WS_FULL, ST_FALLBACK = 1, 2, 4, 8, 16
 ST_COMPACTED, ST_SPILLED = 64, 128
 ST_NONFINITE = 32
@@ -143,6 +143,7 @@ def load_library():
         lib.qmpc_solve_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Inputs),
                                            C.POINTER(Outputs)]
         lib.qmpc_set_debug_clock.argtypes = [C.c_void_p, C.c_void_p]
+        lib.qmpc_debug_read_counts.argtypes = [C.c_void_p, C.c_void_p]
         lib.qmpc_set_max_stance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_min_stance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_pack.argtypes = [C.c_void_p, C.c_int, C.POINTER(Command), C.POINTER(Record), C.c_void_p]
@@ -542,6 +543,13 @@ class BatchedConvexMPC:
                                                   xu.ctypes.data_as(C.c_void_p), hdr.ctypes.data_as(C.c_void_p)),
                     "qmpc_debug_read_item")
         return hinv, xu, hdr
+
+    def debug_read_counts(self):
+        """Test hook: the handle's three per-call counter sets as an int32 [3, 256] array (layout: csrc/qmpc_device.h;
+        sets 0 / 1 alternate between consecutive calls, set 2 serves calls captured into a graph).  Synchronises."""
+        buf = np.zeros((3, 256), np.int32)
+        self._check(self.lib.qmpc_debug_read_counts(self.h, buf.ctypes.data_as(C.c_void_p)), "qmpc_debug_read_counts")
+        return buf
 
     def set_debug_pool_busy(self, on):
         self._check(self.lib.qmpc_set_debug_pool_busy(self.h, int(bool(on))), "qmpc_set_debug_pool_busy")

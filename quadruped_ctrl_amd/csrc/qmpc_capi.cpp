@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../include/qmpc.h"
+#include "../../include/qmpc_debug.h"   // test / profiling hooks (same library)
+#include "../../include/qmpc_expert.h"  // tuning knobs whose default is the measured optimum, warm start
 #include "qmpc_device.h"
 
 // per-class entry points of qmpc_kernels.hip (one translation unit per size class)
@@ -262,7 +264,7 @@ int ensure_pools(qmpc_ctx* c);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 19; }
+int qmpc_abi_version(void) { return 20; }
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -836,7 +838,7 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     cnt = c->d_counts + QMPC_COUNTERS * set;
     cnt_next = c->d_counts + QMPC_COUNTERS * (set ^ 1u);
   }
-  P.ov_count = cnt + 7;                         // slices of the overflow pool handed out in this call
+  P.ov_count = cnt + QMPC_CNT_OV;                         // slices of the overflow pool handed out in this call
   bool first = true;                            // the next launch is the first of the call: it carries clear_counts
 
   // one item class of the decoupled path (sk 0 / 1: sweep kernel of class rb; sk 2: the large-problem producer): the

@@ -26,7 +26,8 @@
 // per-call device counters, one set of QMPC_COUNTERS ints (two sets, ping-ponged between consecutive calls; the first
 // kernel of a chain zeroes the NEXT call's set):
 //   [0..2] list lengths of classes 4, 2, 3   [3] list length of the large problems (horizons > 16, n_r > 192)
-//   [4..6] queue heads of the one-kernel list consumers   [7] overflow-pool slices handed out
+//   [4..6] queue heads of the one-kernel list consumers   [7] overflow-pool slices handed out   [16] / [17] probes that
+//   found a slice taken / robots that timed out waiting for one (QMPC_CNT_OV_*)
 //   [8 + sk] robots the engine kernel of item class sk hands back (sk = 0: 128-row class, 1: 192-row class, 2: large
 //   problems)   [12 + sk] queue heads of the launches that take them
 //   [QMPC_CNT_GRP(sk, g)], g = 0 / 1: one GROUP of counters per chunk in flight of item class sk.  The work items of a class
@@ -39,6 +40,9 @@
 #define QMPC_ORDER_BUCKETS 16
 #define QMPC_GRP_INTS 32
 #define QMPC_CNT_BIGLIST 3
+#define QMPC_CNT_OV 7          // robots that took a slice of the overflow pool in this call
+#define QMPC_CNT_OV_PROBES 16  // ... compare-and-swap probes of theirs that found a slice taken (0 unless the pool is nearly full)
+#define QMPC_CNT_OV_TIMEOUT 17 // ... robots that gave up after ov_spin probes (-> Schur-form fallback, QMPC_ST_FALLBACK)
 #define QMPC_CNT_FB 8
 #define QMPC_CNT_FBQ 12
 #define QMPC_CNT_GRP(sk, g) (64 + QMPC_GRP_INTS * (2 * (sk) + (g)))

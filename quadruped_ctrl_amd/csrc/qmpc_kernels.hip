@@ -2550,7 +2550,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             const unsigned start = P.ov_count ? (unsigned)atomicAdd(P.ov_count, 1) : (unsigned)rid;
             const unsigned ns = (unsigned)P.ov_nslice;
             unsigned idx = start % ns;
-            for (int probe = 0; probe < P.ov_spin; ++probe) {
+            int probe = 0;
+            for (; probe < P.ov_spin; ++probe) {
               if (atomicCAS(&P.ov_flags[idx], 0, 1) == 0) {
                 slice = (int)idx;
                 break;
@@ -2558,8 +2559,17 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
               idx = (idx + 1u == ns) ? 0u : idx + 1u;
               if (idx == start % ns) __builtin_amdgcn_s_sleep(32);  // once round: everything is taken, give the holders time
             }
+            // (statistics of the call, next to the spill counter: probes that found a slice taken, robots that timed out --
+            //  qmpc_debug_read_counts; off the hot path: only a robot that spills gets here)
+            if (P.ov_count && probe > 0) atomicAdd(P.ov_count + (QMPC_CNT_OV_PROBES - QMPC_CNT_OV), probe);
+            if (P.ov_count && slice < 0) atomicAdd(P.ov_count + (QMPC_CNT_OV_TIMEOUT - QMPC_CNT_OV), 1);
           }
           slice = __builtin_amdgcn_readfirstlane(slice);
+          // the slice's previous tenant may have run on another XCD: pair its release (agent-scope fence + flag store) with an
+          // agent-scope acquire, so that nothing this wave reads from the slice later can come from a stale L1 / L2 line
+          // (today every byte of a slice is written by its tenant before it is read -- copy + zero_group -- this keeps it
+          //  correct if that ever changes; spill path only)
+          if (slice >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           if (slice < 0) {
             retry = true;  // no slice (none configured / timed out): the robot is re-run with the Schur-form engine
           } else {

@@ -19,8 +19,14 @@ def _build_once():
 
 def test_library_exports_every_declared_symbol():
     _build_once()
-    hdr = open(os.path.join(ROOT, "include", "qmpc.h")).read()
-    declared = sorted(set(re.findall(r"\b(qmpc_[a-z_]+)\s*\(", hdr)))
+    # the caller's surface (qmpc.h: at most 25 entry points), the expert knobs and the test hooks: three headers, one library
+    decl = lambda f: set(re.findall(r"^(?:int|const char\*) (qmpc_[a-z_]+)\s*\(", open(os.path.join(ROOT, "include", f)).read(), re.M))
+    core, expert, debug = decl("qmpc.h"), decl("qmpc_expert.h"), decl("qmpc_debug.h")
+    assert len(core) <= 25, sorted(core)
+    assert not any(n.startswith(("qmpc_set_debug", "qmpc_debug_")) for n in core | expert)
+    assert all(n.startswith(("qmpc_set_debug", "qmpc_debug_")) for n in debug)
+    assert not (core & expert) and not (core & debug) and not (expert & debug)
+    declared = sorted(core | expert | debug)
     assert set(declared) == set(binding.EXPORTS), (declared, binding.EXPORTS)
     lib = C.CDLL(binding.LIB_PATH)
     for name in declared:
