@@ -162,6 +162,13 @@ def full_shard_compare(b, grf, soln=None):
     return err, bd, capped, whole
 
 
+# robots of the BASELINE shards that exceed north_star's flat 1e-4 (round 5, profiles/r05_j_gpu_tests.txt), with the error
+# measured then; configs[3] (h = 16): (count cap, error cap) -- 226 robots / 1.43e-3 measured
+FLAT_1E4_ALLOW = {1: {}, 2: {771: 2.14e-4, 2407: 1.12e-4},
+                  3: (240, 1.6e-3),
+                  4: {2721: 1.03e-4, 3615: 1.60e-4, 4299: 1.68e-4, 5833: 1.63e-4, 7285: 1.59e-4}}
+
+
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4])
 def test_full_shard_vs_oracle(cfg, mpc_factory):
     """One GPU's FULL shard of every BASELINE config (1024 / 4096 / 4096 at h = 16 / 8192 robots), every
@@ -186,6 +193,18 @@ def test_full_shard_vs_oracle(cfg, mpc_factory):
     assert (err < bd).all()
     # the whole solution, normalised by its own largest entry, holds the flat 1e-4 on every robot of every shard
     assert (whole < 1e-4).all()
+    # north_star's FLAT 1e-4 stays a hard gate for everybody else: at horizon 10 only the robots named here --
+    # measured over it in round 5, each inside the reference's own float-order spread -- may exceed it, and by no more than
+    # they did then (+ 10 %); at horizon 16 the count and the maximum are capped at what was measured (226 robots, 1.43e-3).
+    # A NEW offender, or a known one that got worse, fails whatever its spread is.
+    known = FLAT_1E4_ALLOW[cfg]
+    if isinstance(known, dict):
+        assert set(over.tolist()) <= set(known), sorted(set(over.tolist()) - set(known))
+        for r, worst in known.items():
+            assert err[r] < 1.1 * worst, (r, err[r], worst)
+    else:
+        max_count, max_err = known
+        assert over.size <= max_count and err.max() < max_err, (over.size, err.max())
     if cfg == 2:
         # the robot VERDICT r4 named: over the flat figure, inside the reference's own spread
         assert 1e-4 < err[771] < bd[771]
@@ -1535,6 +1554,11 @@ def test_bench_eight_ranks_config4_dry_run():
     assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
     assert d["gather"]["gathered_rows_match_local_on_every_rank"] is True and d["gather"]["bytes_per_step"] == 8 * 96 * 48
     assert len(d["per_rank"]["elapsed_s"]) == 8
+    # N > 1 readiness: the event-timed value (barrier outside the span) beside the contract value
+    et = d["event_timed"]
+    assert d["value_event_timed"] >= d["value"] * 0.999 and len(et["per_rank_ms_per_step"]) == 8
+    assert abs(d["value_event_timed"] - 8 * 96 / (et["ms_per_step"] * 1e-3)) < 1e-6 * d["value_event_timed"]
+    assert 0.0 <= et["barrier_bias_measured"] < 1.0 and "barrier" in et["barrier_bias_expected"]
     assert [r["rank"] for r in d["rank_devices"]] == list(range(8)) and d["world_size"] == 8
     assert all(r["device_name"] for r in d["rank_devices"]) and d["distinct_devices"] >= 1
 

@@ -218,9 +218,9 @@ def test_bench_whole_shard_parity_names_the_robots_over_the_flat_bound():
     ps = bench.parity_whole_shard(b, fake, first=(ref[:32], nw[:32]))
     assert ps["robots"] == 96 and ps["whole_shard"] and ps["robots_over_1e-4"] == 1 and ps["worst_robots"][0]["robot"] == 7
     assert abs(ps["max_rel_grf_err"] - 3e-4) < 2e-5 and ps["spread_checked_on"] == 1
-    assert ps["all_checked_within_1.5x_reference_spread"] is False       # 3e-4 is not the reference's noise on that robot
+    assert ps["worst_checked_within_1.5x_reference_spread"] is False and ps["spread_unchecked"] == 0 and ps["all_over_1e-4_checked"]       # 3e-4 is not the reference's noise on that robot
     clean = bench.parity_whole_shard(b, ref[:, :12].astype(np.float32))
-    assert clean["robots_over_1e-4"] == 0 and clean["all_checked_within_1.5x_reference_spread"] is True
+    assert clean["robots_over_1e-4"] == 0 and clean["worst_checked_within_1.5x_reference_spread"] is True and clean["spread_unchecked"] == 0
 
 
 def test_bench_cpu_core_accounting():
