@@ -371,6 +371,9 @@ def main():
                     help="'sparse' = the reference's SPARSE formulation (SparseCMPC.cpp:31-73, qmpc_set_model(QMPC_MODEL_SPARSE)) with "
                          "SparseCMPC's own parameters (mu 1, its weights, g = -9.81, ConvexMPCLocomotion.cpp:732-756); the CPU baseline is "
                          "then the reference's OSQP leg (and the dense qpOASES pipeline on the same states beside it)")
+    ap.add_argument("--max-iter", type=int, default=None,
+                    help="census runs (tools/census.sh): cap the active-set iterations (qmpc_settings); robots that need more stop "
+                         "with QMPC_ST_MAXITER -- counters by cap give the cost of ONE iteration as a slope")
     ap.add_argument("--no-hint", action="store_true",
                     help="do not tell the solver the workload's max stance foot-steps (launch every size class)")
     args = ap.parse_args()
@@ -442,6 +445,8 @@ def main():
         mpc.set_robot(9.0, (0.07, 0.26, 0.242), -9.81)   # SparseCMPC.cpp:40
         mpc.set_model(1)
     mpc.set_order_hint(1 if args.order_hint == "auto" else 0)
+    if args.max_iter is not None:
+        mpc.settings(max_iter=args.max_iter)
     d = mpc.upload(b)
     o = mpc.alloc_outputs(per_gpu, full=False, iters=True)
     inp, out = mpc.make_args(d, o)
@@ -728,9 +733,10 @@ def main():
             ok_ = c_[:, 7] > c_[:, 0]
             tot = np.where(ok_, c_[:, 7] - c_[:, 0], 0.0)
             eng = np.where(ok_, c_[:, 6] - c_[:, 5], 0.0)
-            start = np.where(ok_, c_[:, 0], np.inf)
             hard = int(np.argmax(np.where(ok_, it_, -1)))
-            launch_cycles = float((np.where(ok_, c_[:, 7], 0.0)).max() - start.min())
+            # (the shader-clock counters of different XCDs are not synchronised: only differences inside one workgroup mean
+            #  anything.  The launch is as long as its longest workgroup, plus the dispatch skew of ~0.2 - 1.4 us)
+            launch_cycles = float(tot.max())
             # the same robot with a CU to itself: a batch of 64 that starts at its row (rows wrap: any 64 consecutive robots)
             lo = min(hard, per_gpu - 64) if per_gpu >= 64 else 0
             nb = min(64, per_gpu)
@@ -754,7 +760,9 @@ def main():
                     "tail_robot_cycles_in_this_launch": float(tot[hard]), "tail_robot_fixed_part_cycles": float(tot[hard] - eng[hard]),
                     "tail_robot_active_set_cycles": float(eng[hard]),
                     "median_robot_cycles": float(np.median(tot[ok_])), "median_robot_iters": float(np.median(it_[ok_])),
-                    "launch_cycles_first_start_to_last_end": launch_cycles,
+                    "longest_workgroup_cycles": launch_cycles, "longest_workgroup_iters": int(it_[int(np.argmax(tot))]),
+                    "kernel_us_hip_events_unstamped": ev_ms / args.steps * 1e3,
+                    "implied_shader_clock_ghz": launch_cycles / (ev_ms / args.steps * 1e6),
                     "fixed_part_cycles_alone_on_a_cu": fixed_alone, "cycles_per_iteration_alone": per_iter_alone,
                     "implied_floor_cycles": floor, "achieved_over_floor": (launch_cycles / floor if floor else None),
                     "floor_over_achieved": (floor / launch_cycles if floor else None),

@@ -333,6 +333,37 @@ struct Smem {
 #define QMPC_STEP_TICK(k, dep) do { } while (0)
 #endif
 
+// census builds (-DQMPC_STOP_AFTER=<k>, tools/census.sh; never in production): the workgroup leaves solve_one right after stage k
+// (-1: at entry), after a dump that keeps everything the stage produced alive -- every byte of the workgroup's LDS and the given
+// registers are summed into the robot's grf row -- so that the per-stage instruction counts are differences of PMC counters
+// between consecutive builds (the dump is the same in all of them and cancels)
+#ifdef QMPC_STOP_AFTER
+template <int RB, int NV>
+__device__ __forceinline__ void qmpc_census_dump(Smem<RB>& S, const QmpcParams& PK, int rid, int tid, const double (&regs)[NV]) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc += regs[k];
+  const volatile double* lds = reinterpret_cast<const volatile double*>(&S);
+  for (int k = tid; k < (int)(sizeof(Smem<RB>) / 8); k += Cfg<RB>::NT) acc += lds[k];
+  PK.grf[(size_t)rid * 12 + (tid % 12)] = (float)acc;
+  if (tid == 0) {
+    PK.status[rid] = 0;
+    if (PK.iters) PK.iters[rid] = 0;
+  }
+}
+#define QMPC_STOP(k, regs)                                  \
+  do {                                                      \
+    if constexpr (QMPC_STOP_AFTER == (k)) {                 \
+      __syncthreads();                                      \
+      qmpc_census_dump<RB>(S, PK, rid, tid, regs);          \
+      __syncthreads();                                      \
+      return false;                                         \
+    }                                                       \
+  } while (0)
+#else
+#define QMPC_STOP(k, regs) do { } while (0)
+#endif
+
 // CMD selects where the input record comes from: false = loaded (qmpc_solve), true =
 // generated in stage 0 from the controller command (qmpc_solve_commands).
 // V5 selects the active-set engine: true = event form (projected inverse as a
@@ -357,6 +388,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   constexpr int NFG = (4 * HMAX + 63) / 64;  // 64-foot-step groups of the contact table
   long long* dbg_clk = PK.dbg_clk ? PK.dbg_clk + (size_t)rid * 16 : nullptr;
   QMPC_TICK(0);
+  {
+    const double none[1] = {0.0};
+    (void)none;
+    QMPC_STOP(-1, none);
+  }
 #if QMPC_SWEEP_PRIO && QMPC_START_PRIO
   __builtin_amdgcn_s_setprio(3);  // a workgroup that is just starting is behind everybody else on its CU
 #endif
@@ -660,6 +696,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
   __syncthreads();  // ---- barrier 1
   QMPC_TICK(1);
+  {
+    const double keep0[2] = {(double)g_alpha, x_drag};
+    (void)keep0;
+    QMPC_STOP(0, keep0);
+  }
 #if QMPC_SWEEP_PRIO && QMPC_START_PRIO
   // one-round launch with the order hint: everybody started at the highest priority (a tie); from here to the sweep the
   // robots the previous call did not find hard step back one level (the hint's two scalar loads have landed with the record)
@@ -780,6 +821,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   }
   __syncthreads();  // ---- barrier 2
   QMPC_TICK(2);
+  {
+    const double keep1[2] = {alpha, x_drag};
+    (void)keep1;
+    QMPC_STOP(1, keep1);
+  }
   if constexpr (PHA) {
     // (the pool of work items is bounded and the host never launches more robots per chunk than it holds; an index
     //  beyond it means corrupt counters: the robot is reported, nothing is written out of bounds)
@@ -1335,6 +1381,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     if (tid < NP) P.dbg_g[(size_t)rid * QMPC_DBG_LD + tid] = Sw.g[tid];
   }
   QMPC_TICK(3);
+  QMPC_STOP(2, a);
 
   // ------------------------------------------------------------ stage 3
   // Symmetric Gauss-Jordan sweeps, TWO pivots per barrier: a <- -H^-1.
@@ -1351,19 +1398,32 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   if constexpr (C::C1) {
     // Class 1: a column group is exactly one wave (lane == row), so the wave that
     // owns the NEXT pivot pair reads its 2x2 pivot block with readlane, inverts it
-    // once, and publishes F = C P^-1 (with the pivot-row correction folded in) next
-    // to the pivot columns.  The other three waves only load and do the 2 fma per
-    // element: the reciprocal and the F arithmetic are not replicated 4x.
-    double sv0 = 0.0, sv1 = 0.0;  // pivot-column registers' new values, kept by the producing wave
+    // once, and publishes the pivot columns and F = C P^-1 for everybody.  The other
+    // three waves only load and do the 2 fma per element: the reciprocal and the F
+    // arithmetic are not replicated 4x.
+    // SYMMETRIC form (round 6).  With C' = C - [e_k0 e_k1] (the pivot columns with 1 subtracted from their
+    // own diagonal entries) used BOTH as the broadcast vector and in F' = C' P^-1,
+    //     A - F' C'^T = A - C' P^-1 C'^T
+    // IS the sweep result in the pivot rows (C_j - P P^-1 C_j + P^-1 C_j), in the pivot columns (their transpose) and
+    // everywhere else; only the 2 x 2 pivot block comes out as 2 I - P^-1 instead of -P^-1, and the producing wave
+    // subtracts 2 from those two diagonal entries when it reads the pair (the update is additive: any time will do).
+    // Until round 5 the pivot rows took a corrected F (twelve selects in the producing wave) and the pivot columns were
+    // written back explicitly by their owner -- four selects and four moves in EVERY wave and pair, because the owner
+    // test is a vector compare: 22 + 8 of the ~85 vector instructions of the producing wave's pair, 8 of the other
+    // waves' 44.  A launch of several rounds is paced by exactly that instruction stream (five workgroups share a CU:
+    // a wave issues every ~12 cycles, whatever it issues).  Same arithmetic otherwise; results agree with the previous
+    // form to rounding (1e-13 relative in H^-1), not bit for bit.
     // the pivot arithmetic in stages, so that the producing wave can slot the rest
     // of its update into the latencies of this dependent chain
-    double pd0, pe, pd1, pdet, px, pc0, pc1;
+    double pd0, pe, pd1, pdet, px, pc0, pc1, pm0, pm1;
     auto prod_read = [&](double c0n, double c1n, int k0n) __attribute__((always_inline)) {
-      pc0 = c0n;
-      pc1 = c1n;
       pd0 = readlane_f64(c0n, k0n);
       pe = readlane_f64(c0n, k0n + 1);   // A[k1][k0]   (k1 == n: identity padding column, a no-op pivot)
       pd1 = readlane_f64(c1n, k0n + 1);
+      pm0 = (i == k0n) ? 1.0 : 0.0;
+      pm1 = (i == k0n + 1) ? 1.0 : 0.0;
+      pc0 = c0n - pm0;  // C'
+      pc1 = c1n - pm1;
     };
     // 2x2 pivot block P = [[d0, e], [e, d1]] inverted through its determinant:
     // ONE reciprocal on the critical path.  P^-1 = idet [[d1, -e], [-e, d0]].
@@ -1376,35 +1436,29 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       const double e1 = __builtin_fma(-pdet, px, 1.0);
       px = __builtin_fma(px, e1, px);
     };
-    double pfg0, pfg1, pq0, pq1;  // F_i0, F_i1 and the pivot-row corrections of this row
-    auto prod_fg = [&](int k0n) __attribute__((always_inline)) {
+    double pnf0, pnf1;  // -F'_i0, -F'_i1 (negated: the update is a += c' * (-F'))
+    auto prod_fg = [&]() __attribute__((always_inline)) {
       const double i11 = pd1 * px, i01 = pe * px, i00 = pd0 * px;  // +-entries of P^-1
-      // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i
-      pfg0 = __builtin_fma(i11, pc0, -i01 * pc1);
-      pfg1 = __builtin_fma(i00, pc1, -i01 * pc0);
-      const bool p0 = (i == k0n), p1 = (i == k0n + 1);
-      pq0 = p0 ? -i11 : (p1 ? i01 : 0.0);
-      pq1 = p0 ? i01 : (p1 ? -i00 : 0.0);
+      // F' = C' P^-1 for this row:  F'_i0 = i11 c0'_i - i01 c1'_i ,  F'_i1 = i00 c1'_i - i01 c0'_i
+      pnf0 = __builtin_fma(-i11, pc0, i01 * pc1);
+      pnf1 = __builtin_fma(-i00, pc1, i01 * pc0);
     };
-    auto prod_store = [&](int k0n, int mn) __attribute__((always_inline)) {
-      const bool pr = (i == k0n) | (i == k0n + 1);
-      // pivot columns <- F, pivot block <- -P^-1
-      sv0 = pr ? pq0 : pfg0;
-      sv1 = pr ? pq1 : pfg1;
-      // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j)
+    auto prod_store = [&](int mn) __attribute__((always_inline)) {
       Sw.colbuf[mn & 1][0][i] = pc0;
       Sw.colbuf[mn & 1][1][i] = pc1;
-      Sw.ubuf[mn & 1][0][i] = -(pfg0 + pq0);  // stored negated: the update is a += c * (-F)
-      Sw.ubuf[mn & 1][1][i] = -(pfg1 + pq1);
+      Sw.ubuf[mn & 1][0][i] = pnf0;
+      Sw.ubuf[mn & 1][1][i] = pnf1;
     };
     if (c == 0) {
       prod_read(a[0], a[1], 0);
+      a[0] = __builtin_fma(-2.0, pm0, a[0]);  // the pivot block's diagonal: 2 I - P^-1 -> -P^-1
+      a[1] = __builtin_fma(-2.0, pm1, a[1]);
       prod_det();
       prod_rcp();
       prod_newton();
       prod_newton();
-      prod_fg(0);
-      prod_store(0, 0);
+      prod_fg();
+      prod_store(0);
     }
     __syncthreads();
 #define QMPC_PIN __builtin_amdgcn_sched_barrier(0)
@@ -1422,7 +1476,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       else __builtin_amdgcn_s_setprio(0);
 #endif
       StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
-        constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
+        constexpr int r0 = 2 * decltype(pc)::value;
         constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
         constexpr int G0 = 4 * (rn0 / 4), G1 = (G0 + 4) % 16, G2 = (G0 + 8) % 16, G3 = (G0 + 12) % 16;
         const int k0 = kb * CW + r0;
@@ -1431,8 +1485,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           // lane l holds pivot-column entry c*16 + l%16 (the 16 columns of this wave)
           const double cv0 = Sw.colbuf[m & 1][0][c * CW + (lane & 15)];
           const double cv1 = Sw.colbuf[m & 1][1][c * CW + (lane & 15)];
-          const double nu0 = Sw.ubuf[m & 1][0][i], nu1 = Sw.ubuf[m & 1][1][i];  // -F_i0, -F_i1
-          const double so0 = sv0, so1 = sv1;
+          const double nu0 = Sw.ubuf[m & 1][0][i], nu1 = Sw.ubuf[m & 1][1][i];  // -F'_i0, -F'_i1
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
             // this wave owns the next pivot pair: its two columns first, then the
@@ -1441,6 +1494,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             fmac4_rowbcast<G0>(a, cv1, nu1);
             QMPC_PIN;
             prod_read(a[rn0], a[rn1], k0 + 2);
+            a[rn0] = __builtin_fma(-2.0, pm0, a[rn0]);
+            a[rn1] = __builtin_fma(-2.0, pm1, a[rn1]);
             QMPC_PIN;
             fmac4_rowbcast<G1>(a, cv0, nu0);
             QMPC_PIN;
@@ -1457,11 +1512,11 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             QMPC_PIN;
             fmac4_rowbcast<G2>(a, cv1, nu1);
             QMPC_PIN;
-            prod_fg(k0 + 2);
+            prod_fg();
             QMPC_PIN;
             fmac4_rowbcast<G3>(a, cv0, nu0);
             QMPC_PIN;
-            prod_store(k0 + 2, m + 1);
+            prod_store(m + 1);
             QMPC_PIN;
             fmac4_rowbcast<G3>(a, cv1, nu1);
           } else if (c * CW < n) {
@@ -1469,10 +1524,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             //  its pivot-column entries are zero)
             fmac16_rowbcast(a, cv0, nu0);
             fmac16_rowbcast(a, cv1, nu1);
-          }
-          if (c == kb) {
-            a[r0] = so0;
-            a[r1] = so1;
           }
           __syncthreads();
         }
@@ -1505,11 +1556,18 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // ... and ONE number whose sign says whether both pivots were positive (a NaN fails the readers' test as well)
       st2(pv + 2, d0 * idet, (d0 < det) ? d0 : det);  // (ordered compare: a NaN determinant is what gets stored)
     };
+    // SYMMETRIC form (round 6; the class-1 branch above has the derivation): the pivot columns are published with 1 subtracted
+    // from their own diagonal entries, C' = C - [e_k0 e_k1]; every thread's F' = C' P^-1 then carries the pivot rows' correction
+    // by itself, the update A - F' C'^T leaves F in the pivot columns by itself, and the publishing thread subtracts 2 from the
+    // pivot block's two diagonal entries (2 I - P^-1 -> -P^-1).  No pivot-row branch, no pivot-column write-back.
     if (c == 0) {
-      Sw.colbuf[0][0][i] = a[0];
-      Sw.colbuf[0][1][i] = a[1];
+      const double pm0 = (i == 0) ? 1.0 : 0.0, pm1 = (i == 1) ? 1.0 : 0.0;
+      Sw.colbuf[0][0][i] = a[0] - pm0;
+      Sw.colbuf[0][1][i] = a[1] - pm1;
       const double e_n = lane_next(a[0]), d1_n = lane_next(a[1]);
       if (i == 0) publish_pinv(a[0], e_n, d1_n, 0);
+      a[0] = __builtin_fma(-2.0, pm0, a[0]);
+      a[1] = __builtin_fma(-2.0, pm1, a[1]);
     }
     __syncthreads();
 #pragma unroll 1
@@ -1522,9 +1580,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       else __builtin_amdgcn_s_setprio(0);
 #endif
       StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
-        constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
+        constexpr int r0 = 2 * decltype(pc)::value;
         constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
-        const int k0 = kb * CW + r0, k1 = k0 + 1;  // k1 == n: identity padding column, a no-op pivot
+        const int k0 = kb * CW + r0;  // (k0 + 1 == n: identity padding column, a no-op pivot)
         if (k0 < n) {
           const int m = k0 >> 1;
           QMPC_STEP_TICK(0, 0.0);
@@ -1554,19 +1612,10 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           notpd |= !(pv[3] > 0.0);
           // F = C P^-1 for this row:  F_i0 = i11 c0_i - i01 c1_i ,  F_i1 = i00 c1_i - i01 c0_i ; kept NEGATED (the
           // update is a += c * (-F): the sign goes into the fma instead of into extra instructions)
-          const double nf0 = __builtin_fma(-i11, c0i, i01 * c1i);
-          const double nf1 = __builtin_fma(-i00, c1i, i01 * c0i);
-          QMPC_STEP_TICK(1, nf0 + nf1);
-          const bool p0 = (i == k0), p1 = (i == k1);
-          // pivot rows: a_kj <- (P^-1 C^T)_kj == a_kj - ((I - P^-1) C^T)_kj   (a_kj == c_j).  Two lanes of ONE
-          // wave: a branch the other waves skip, instead of eight selects in every lane of every wave (the step is
-          // bound by VALU issue: ~55 of its ~105 vector instructions per wave were not the fmacs)
-          double nu0 = nf0, nu1 = nf1;
-          if (p0 | p1) {
-            asm volatile("" ::: "memory");  // (keeps the block a branch: it would be if-converted into selects)
-            nu0 = nf0 + (p0 ? i11 : -i01);
-            nu1 = nf1 + (p0 ? -i01 : i00);
-          }
+          // (c0i, c1i are C': the pivot rows' correction is in F' already)
+          const double nu0 = __builtin_fma(-i11, c0i, i01 * c1i);
+          const double nu1 = __builtin_fma(-i00, c1i, i01 * c0i);
+          QMPC_STEP_TICK(1, nu0 + nu1);
           // The thread's columns in groups of 16 (class 4: 16 + 8): a group's pivot-column values are held one per lane of
           // a row of 16 (8) and broadcast inside the DPP fmac.  Only the TWO columns of the next pivot pair are updated
           // before their owner publishes them and the inverse of their 2 x 2 block -- four fmacs on the step's critical
@@ -1578,10 +1627,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           QMPC_STEP_TICK(2, a[rn0] + a[rn1]);
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
-            Sw.colbuf[(m + 1) & 1][0][i] = a[rn0];
-            Sw.colbuf[(m + 1) & 1][1][i] = a[rn1];
+            const double pm0 = (i == k0 + 2) ? 1.0 : 0.0, pm1 = (i == k0 + 3) ? 1.0 : 0.0;
+            Sw.colbuf[(m + 1) & 1][0][i] = a[rn0] - pm0;  // C'
+            Sw.colbuf[(m + 1) & 1][1][i] = a[rn1] - pm1;
             const double e_n = lane_next(a[rn0]), d1_n = lane_next(a[rn1]);  // A[k1'][k0'], A[k1'][k1'] of the next pair
             if (i == k0 + 2) publish_pinv(a[rn0], e_n, d1_n, (m + 1) & 1);
+            a[rn0] = __builtin_fma(-2.0, pm0, a[rn0]);  // the pivot block's diagonal: 2 I - P^-1 -> -P^-1
+            a[rn1] = __builtin_fma(-2.0, pm1, a[rn1]);
           }
           QMPC_STEP_TICK(3, 0.0);
           __builtin_amdgcn_sched_barrier(0);
@@ -1608,16 +1660,6 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             }
           });
           QMPC_STEP_TICK(4, a[0] + a[CW - 1] + a[CW / 2]);
-          if (c == kb) {
-            // pivot columns <- F, pivot block <- -P^-1
-            a[r0] = -nf0;
-            a[r1] = -nf1;
-            if (p0 | p1) {
-              asm volatile("" ::: "memory");
-              a[r0] = p0 ? -i11 : i01;
-              a[r1] = p0 ? i01 : -i00;
-            }
-          }
           __syncthreads();
           QMPC_STEP_TICK(5, 0.0);
         }
@@ -1626,6 +1668,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   }
   if (notpd) S.status = QMPC_DEV_ST_NOT_PD;  // benign race: same value from every thread
   QMPC_TICK(4);
+  QMPC_STOP(3, a);
 
   auto& Sb = S.u.b;
   // ------------------------------------------------------------ stage 4
@@ -1730,38 +1773,32 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     // it pre-computed during assembly across the whole sweep (they were spilled)
     int io = i, co = c * CW;
     asm volatile("" : "+v"(io), "+v"(co));
-    const int rb = io * (io + 1) / 2;
+    // (one compare against a literal per element -- d >= jj -- and one base address: the dump is ~4 % of the kernel's vector
+    //  instructions; the registers are negated in place, nothing reads them afterwards)
+    const int dd = io - co;
+    double* const hrow = Sb.Hp + (io * (io + 1) / 2 + co);
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) {
-      const int j = co + jj;
-      if (j <= io) Sb.Hp[rb + j] = -a[jj];
+      if (dd >= jj) hrow[jj] = -a[jj];
       if ((jj & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
   if constexpr (V5) {
-    if constexpr (!C::GLOBAL_EVENTS)
-      for (int k = tid; k < C::NPOOL; k += NT) Sb.Sinv[k] = 0.0;  // event rows start out zero
+    if constexpr (!C::GLOBAL_EVENTS) {
+      static_assert(C::NPOOL % 2 == 0 && C::NH % 2 == 0, "16-byte stores into the event pool");
+      for (int k = 2 * tid; k < C::NPOOL; k += 2 * NT) st2(&Sb.Sinv[k], 0.0, 0.0);  // event rows start out zero
+    }
   } else {
     // packed S_W^-1 behind the n(n+1)/2 doubles of the inverse (see stage 5)
     const int nh0 = n * (n + 1) / 2, cap0 = C::NH + C::NPOOL - nh0;
     for (int k = tid; k < (cap0 < C::NS ? cap0 : C::NS); k += NT) Sb.Hp[nh0 + k] = 0.0;
   }
-  if constexpr (V5) {
-    // diagonal of H^-1: entry (i,i) is register i % CW of column group i / CW
-    if (c == i / CW) {
-      const int r = i % CW;
-      double v = a[0];
-#pragma unroll
-      for (int q = 1; q < CW; ++q) {
-        double t = a[q];
-        asm volatile("" : "+v"(t));
-        v = (r == q) ? t : v;
-      }
-      Sb.D[i] = -v;
-    }
-  }
+  // (diag(H^-1), which the event engine scales its dependence test with, is read from the packed inverse where it is needed --
+  //  entry (j, j) at j (j + 3) / 2, a scalar address -- instead of being collected here through a sixteen-way register select in
+  //  every wave: 190 vector instructions per robot; Sb.D stays as the ADMM engine's / the output stage's scratch)
   __syncthreads();
   QMPC_TICK(5);
+  QMPC_STOP(4, xv);
 
   // ------------------------------------------------------------ stage 5 (event form)
   // Goldfarb-Idnani with the projected inverse kept as a SUM OF EVENTS.  Every
@@ -2414,7 +2451,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           }
           if (!helped) ev_part(gpc, pool, pj1, pj2, pa1, pa2, neva, nevd, 0, 1, z, rw);
           const double delta = __builtin_fma(pa2, bcast(z, pj2), pa1 * bcast(z, pj1));
-          const double cn = __builtin_fma(pa2 * pa2, Sb.D[pj2], pa1 * pa1 * Sb.D[pj1]);  // scale of c_p^T H^-1 c_p
+          const double cn = __builtin_fma(pa2 * pa2, Sb.Hp[pj2 * (pj2 + 3) / 2], pa1 * pa1 * Sb.Hp[pj1 * (pj1 + 3) / 2]);  // scale of c_p^T H^-1 c_p: diag(H^-1)
           const double sp = __builtin_fma(pa2, bcast(xv, pj2), pa1 * bcast(xv, pj1)) - p_rhs;
           if (dbg_clk && lane == 0 && iters == QMPC_DBG_ITER) dbg_clk[9] = clock64();
           const bool dep = uni(!(delta > 1e-11 * cn));

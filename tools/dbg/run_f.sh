@@ -1,0 +1,12 @@
+mkdir -p gpurun_out/r06_f
+/opt/rocm/bin/hipcc -O3 -std=c++17 -Wno-unused-value --offload-arch=gfx950 tools/ubench/mfma_sweep.hip -o /tmp/mfma_sweep && timeout 300 /tmp/mfma_sweep > gpurun_out/r06_f/ubench_a2.txt 2>&1
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r06_f/gpu_tests.txt 2>&1
+tail -5 gpurun_out/r06_f/gpu_tests.txt
+for a in "--steps 200" "--config 2 --steps 100" "--config 3 --steps 50" "--config 4 --steps 50" "--batch 16384 --steps 50"; do python bench.py $a --no-cpu-baseline --no-pipelined --no-closed-loop 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$a', '%.4e QP/s %.4f ms' % (d['value'], d['ms_per_step']), 'hinted', (d['order_hint'].get('hinted_same_inputs') or {}).get('value'), 'fail', d['config']['failed'])
+"; done > gpurun_out/r06_f/bench_quick.txt 2>&1
+cat gpurun_out/r06_f/bench_quick.txt
+grep -E "A:shipped|A2:symm|A - A2" gpurun_out/r06_f/ubench_a2.txt

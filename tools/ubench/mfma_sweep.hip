@@ -213,6 +213,137 @@ __global__ __launch_bounds__(256, 5) void sweep_a(long long* clk, double* out, i
   if (notpd && tid == 0) clk[blockIdx.x] = -1;
 }
 
+// ------------------------------------------------------------------ A2: the shipped sweep, symmetric pivot handling
+__global__ __launch_bounds__(256, 5) void sweep_a2(long long* clk, double* out, int n, int nout) {
+  __shared__ SmemA S;
+  const int tid = threadIdx.x, lane = tid & 63, i = tid % NP, c = tid / NP;
+  const int seed = blockIdx.x & 1023;
+  double a[CW];
+#pragma unroll
+  for (int jj = 0; jj < CW; ++jj) a[jj] = hmat(i, c * CW + jj, n, seed);
+  if (tid == 0) S.pad[0] = 0;
+  __syncthreads();
+  const long long t0 = clock64();
+  bool notpd = false;
+  {
+    // SYMMETRIC form (round 6): with C' = C - [e_k0 e_k1] used BOTH as the broadcast vector and in F' = C' P^-1,
+    //   A - F' C'^T  is the sweep result everywhere except the 2 x 2 pivot block, which comes out 2 I - P^-1: the producer
+    //   subtracts 2 from its two diagonal entries when it reads the pair.  No pivot-row selects, no pivot-column write-back.
+    double pd0, pe, pd1, pdet, px, pc0, pc1, pm0, pm1;
+    auto prod_read = [&](double c0n, double c1n, int k0n) __attribute__((always_inline)) {
+      pd0 = readlane_f64(c0n, k0n);
+      pe = readlane_f64(c0n, k0n + 1);
+      pd1 = readlane_f64(c1n, k0n + 1);
+      pm0 = (i == k0n) ? 1.0 : 0.0;
+      pm1 = (i == k0n + 1) ? 1.0 : 0.0;
+      pc0 = c0n - pm0;
+      pc1 = c1n - pm1;
+    };
+    auto prod_det = [&]() __attribute__((always_inline)) {
+      pdet = __builtin_fma(pd0, pd1, -pe * pe);
+      notpd |= !(pd0 > 0.0) | !(pdet > 0.0);
+    };
+    auto prod_rcp = [&]() __attribute__((always_inline)) { px = __builtin_amdgcn_rcp(pdet); };
+    auto prod_newton = [&]() __attribute__((always_inline)) {
+      const double e1 = __builtin_fma(-pdet, px, 1.0);
+      px = __builtin_fma(px, e1, px);
+    };
+    double nf0, nf1;  // -F'_i0, -F'_i1
+    auto prod_fg = [&](int k0n) __attribute__((always_inline)) {
+      const double i11 = pd1 * px, i01 = pe * px, i00 = pd0 * px;
+      nf0 = __builtin_fma(-i11, pc0, i01 * pc1);
+      nf1 = __builtin_fma(-i00, pc1, i01 * pc0);
+    };
+    auto prod_store = [&](int k0n, int mn) __attribute__((always_inline)) {
+      S.colbuf[mn & 1][0][i] = pc0;
+      S.colbuf[mn & 1][1][i] = pc1;
+      S.ubuf[mn & 1][0][i] = nf0;
+      S.ubuf[mn & 1][1][i] = nf1;
+    };
+    if (c == 0) {
+      prod_read(a[0], a[1], 0);
+      a[0] = __builtin_fma(-2.0, pm0, a[0]);
+      a[1] = __builtin_fma(-2.0, pm1, a[1]);
+      prod_det();
+      prod_rcp();
+      prod_newton();
+      prod_newton();
+      prod_fg(0);
+      prod_store(0, 0);
+    }
+    __syncthreads();
+#define QMPC_PIN __builtin_amdgcn_sched_barrier(0)
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {
+      StaticFor<0, CW / 2>::run([&](auto pc) __attribute__((always_inline)) {
+        constexpr int r0 = 2 * decltype(pc)::value, r1 = r0 + 1;
+        constexpr int rn0 = (r0 + 2 < CW) ? r0 + 2 : 0, rn1 = rn0 + 1;
+        constexpr int G0 = 4 * (rn0 / 4), G1 = (G0 + 4) % 16, G2 = (G0 + 8) % 16, G3 = (G0 + 12) % 16;
+        const int k0 = kb * CW + r0;
+        if (k0 < n) {
+          const int m = k0 >> 1;
+          const double cv0 = S.colbuf[m & 1][0][c * CW + (lane & 15)];
+          const double cv1 = S.colbuf[m & 1][1][c * CW + (lane & 15)];
+          const double nu0 = S.ubuf[m & 1][0][i], nu1 = S.ubuf[m & 1][1][i];
+          const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
+          if (k0 + 2 < n && c == kbn) {
+            fmac4_rowbcast<G0>(a, cv0, nu0);
+            fmac4_rowbcast<G0>(a, cv1, nu1);
+            QMPC_PIN;
+            prod_read(a[rn0], a[rn1], k0 + 2);
+            a[rn0] = __builtin_fma(-2.0, pm0, a[rn0]);
+            a[rn1] = __builtin_fma(-2.0, pm1, a[rn1]);
+            QMPC_PIN;
+            fmac4_rowbcast<G1>(a, cv0, nu0);
+            QMPC_PIN;
+            prod_det();
+            prod_rcp();
+            QMPC_PIN;
+            fmac4_rowbcast<G1>(a, cv1, nu1);
+            QMPC_PIN;
+            prod_newton();
+            QMPC_PIN;
+            fmac4_rowbcast<G2>(a, cv0, nu0);
+            QMPC_PIN;
+            prod_newton();
+            QMPC_PIN;
+            fmac4_rowbcast<G2>(a, cv1, nu1);
+            QMPC_PIN;
+            prod_fg(k0 + 2);
+            QMPC_PIN;
+            fmac4_rowbcast<G3>(a, cv0, nu0);
+            QMPC_PIN;
+            prod_store(k0 + 2, m + 1);
+            QMPC_PIN;
+            fmac4_rowbcast<G3>(a, cv1, nu1);
+          } else if (c * CW < n) {
+            fmac16_rowbcast(a, cv0, nu0);
+            fmac16_rowbcast(a, cv1, nu1);
+          }
+          __syncthreads();
+        }
+      });
+    }
+#undef QMPC_PIN
+  }
+  // the inverse leaves the registers: packed lower triangle in LDS (stage 4 of the real kernel, without x_u)
+  if (i < n) {
+    const int rb = i * (i + 1) / 2;
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj) {
+      const int j = c * CW + jj;
+      if (j <= i) S.Hp[rb + j] = -a[jj];
+    }
+  }
+  __syncthreads();
+  const long long t1 = clock64();
+  if (tid == 0) clk[blockIdx.x] = t1 - t0;
+  if ((int)blockIdx.x < nout)
+    for (int k = tid; k < n * (n + 1) / 2; k += 256) out[(size_t)blockIdx.x * (NP * (NP + 1) / 2) + k] = S.Hp[k];
+  if (notpd && tid == 0) clk[blockIdx.x] = -1;
+}
+
+
 // ------------------------------------------------------------------ B: tiles on the matrix cores, four pivots per step
 constexpr int TS = 16 * 17;  // a staged tile: column-major with a stride of 17 (conflict-free for writers AND readers)
 struct SmemB {
@@ -666,6 +797,14 @@ int main() {
     hipMemset(dout, 0, 8 * 8 * (NP * (NP + 1) / 2));
     bench("A:shipped", sweep_a, n, dclk, dout, &ka);
     hipMemset(dout, 0, 8 * 8 * (NP * (NP + 1) / 2));
+    std::vector<double> ka2;
+    hipMemset(dout, 0, 8 * 8 * (NP * (NP + 1) / 2));
+    bench("A2:symm", sweep_a2, n, dclk, dout, &ka2);
+    {
+      double da = 0.0;
+      for (size_t k = 0; k < ka.size(); ++k) da = std::max(da, std::fabs(ka[k] - ka2[k]));
+      printf("n=%d  max |A - A2| = %.3e\n", n, da);
+    }
     bench("B:mfma", sweep_b<0>, n, dclk, dout, &kb);
     std::vector<double> kc;
     hipMemset(dout, 0, 8 * 8 * (NP * (NP + 1) / 2));
