@@ -1437,11 +1437,16 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       px = __builtin_fma(px, e1, px);
     };
     double pnf0, pnf1;  // -F'_i0, -F'_i1 (negated: the update is a += c' * (-F'))
+    double pt0, pt1;    // the adjugate's part of it, which does not wait for the reciprocal
+    // F' = C' P^-1 = C' adj(P) / det:  F'_i0 = (d1 c0'_i - e c1'_i) / det ,  F'_i1 = (d0 c1'_i - e c0'_i) / det.  The two
+    // numerators are formed while the reciprocal's Newton steps are in flight; one multiplication each is all that follows it
+    auto prod_adj = [&]() __attribute__((always_inline)) {
+      pt0 = __builtin_fma(pe, pc1, -pd1 * pc0);
+      pt1 = __builtin_fma(pe, pc0, -pd0 * pc1);
+    };
     auto prod_fg = [&]() __attribute__((always_inline)) {
-      const double i11 = pd1 * px, i01 = pe * px, i00 = pd0 * px;  // +-entries of P^-1
-      // F' = C' P^-1 for this row:  F'_i0 = i11 c0'_i - i01 c1'_i ,  F'_i1 = i00 c1'_i - i01 c0'_i
-      pnf0 = __builtin_fma(-i11, pc0, i01 * pc1);
-      pnf1 = __builtin_fma(-i00, pc1, i01 * pc0);
+      pnf0 = pt0 * px;
+      pnf1 = pt1 * px;
     };
     auto prod_store = [&](int mn) __attribute__((always_inline)) {
       Sw.colbuf[mn & 1][0][i] = pc0;
@@ -1455,6 +1460,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       a[1] = __builtin_fma(-2.0, pm1, a[1]);
       prod_det();
       prod_rcp();
+      prod_adj();
       prod_newton();
       prod_newton();
       prod_fg();
@@ -1501,6 +1507,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             QMPC_PIN;
             prod_det();
             prod_rcp();
+            prod_adj();
             QMPC_PIN;
             fmac4_rowbcast<G1>(a, cv1, nu1);
             QMPC_PIN;
