@@ -92,6 +92,9 @@ int qmpc_set_warm_start(qmpc_handle h, int32_t* ws_dev, int shift_steps);
  * iterations in the handle's previous call (the counts the order hint keeps, qmpc_set_order_hint must be on) read their
  * previous working set; all others start cold -- a launch waits for its hardest robot, and the easy majority only pays for
  * wrong guesses.  0 (default): every robot starts warm while a buffer is set.  Same unique minimiser either way.
+ * The counts exist while the order hint is on (QMPC_ERR_STATE otherwise), for eager calls, from the handle's previous call of
+ * the SAME batch size; a call without them -- the first one, another batch size, a call captured into a hipGraph -- starts
+ * every robot cold.
  * Measured on closed-loop rollouts (profiles/r05_b_warm_select.txt): NOT faster -- the launch's maximum iteration count
  * goes UP with a warm start (17 -> 22, 28 -> 38), whoever else starts cold; kept as an option, off by default. */
 int qmpc_set_warm_start_min_iters(qmpc_handle h, int min_iters);

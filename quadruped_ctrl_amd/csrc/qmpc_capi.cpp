@@ -182,6 +182,7 @@ struct qmpc_ctx {
   int* d_ovflags = nullptr;    // [ov_nslice_alloc] 0 = free
   int ov_nslice = 0;
   int ov_spin = 1 << 22;       // probes of a robot that finds every slice taken before it gives up (test hook: qmpc_set_debug_overflow_slices)
+  bool device_error = false;   // a HIP call of this handle failed since the last successful solve (fail()): see solve_impl
   int* d_evflags = nullptr;
   int ev_nslot = 0;
   bool dbg_pool_busy = false;  // test hook: every slice of the 192-row class's pool looks taken (qmpc_set_debug_pool_busy)
@@ -224,6 +225,7 @@ struct DeviceGuard {
 
 int fail(qmpc_ctx* c, hipError_t e, const char* what) {
   c->err = std::string(what) + ": " + hipGetErrorString(e);
+  c->device_error = true;  // (the next solve re-arms the device state a failed launch chain may have left behind)
   return QMPC_ERR_DEVICE;
 }
 
@@ -300,8 +302,11 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
     c->block = nb && nb[0] == '1';
   }
   if (e == hipSuccess) {
-    // a robot whose on-chip event pool fills up continues here; more than ov_nslice of them in one launch chain
-    // fall back to the Schur-form engine
+    // a robot whose on-chip event pool fills up continues here.  The slices are RECYCLED within a call (one flag per slice,
+    // taken with a compare-and-swap, released when its robot is done): ov_nslice bounds the robots that hold one AT THE SAME
+    // TIME, not the robots of a call; a robot that finds every slice taken waits (ov_spin probes), then falls back to the
+    // Schur-form engine.  Every flag is 0 between calls; after a call that ended in a device error they are re-armed
+    // (solve_impl) -- a flag left at 1 would otherwise be lost for the life of the handle
     // (2048 slices of 192 KiB: what a call of 8192 robots needs when the 64-row class runs five per CU ahead of larger
     //  classes -- see the launch loop of solve_impl)
     c->ov_nslice = max_batch < 2048 ? max_batch : 2048;
@@ -485,6 +490,7 @@ int qmpc_set_warm_start(qmpc_handle c, int32_t* ws_dev, int shift_steps) {
 
 int qmpc_set_warm_start_min_iters(qmpc_handle c, int min_iters) {
   if (!c || min_iters < 0) return QMPC_ERR_ARG;
+  if (min_iters > 0 && !c->order_hint) return QMPC_ERR_STATE;  // the selection reads the counts the order hint keeps
   c->ws_min_iters = min_iters;
   return QMPC_OK;
 }
@@ -744,6 +750,13 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   const int h = c->horizon;
   const bool capturing = is_capturing(stream);
   if (const int rc = order_after_previous(c, stream)) return rc;
+  if (c->device_error && !capturing) {
+    // the previous call (or set-up step) of this handle failed on the device: whatever its kernels left in the
+    // recycled-slice flags and the per-CU placement words is void.  Re-armed with the fill kernel (no memset node: they
+    // replay wrongly when captured, and this path must not differ from the normal one in kind)
+    if (c->d_ovflags && c->ov_nslice > 0) HIP_TRY(c, fill_ints(c->d_ovflags, c->max_batch < 2048 ? c->max_batch : 2048, 0, stream));
+    c->device_error = false;
+  }
 
   QmpcParams P;
   std::memset(&P, 0, sizeof(P));
@@ -784,7 +797,10 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.tol = c->tol;
   P.ws = c->ws;
   P.ws_shift = c->ws_shift;
-  P.ws_min_iters = c->ws_min_iters;
+  // selective warm start: the selection reads the previous call's iteration counts, which exist only while the order hint is on,
+  // the call is eager (not captured) and the previous call had this batch size; without them NOBODY qualifies (every robot
+  // starts cold) -- eager and captured calls, first and later calls behave alike
+  P.ws_min_iters = (c->ws_min_iters > 0 && !(c->order_hint && !capturing && c->hint_batch == batch)) ? 0x7fffffff : c->ws_min_iters;
   if (c->admm_mode && in) {  // (record mode only: the command mode always solves exactly)
     P.admm_mode = c->admm_mode;
     P.admm_max_iter = c->admm_max_iter;
@@ -798,6 +814,9 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
   P.dbg_aux = c->dbg_aux;
   P.dbg_clk = c->dbg_clk;
   P.hint_iters = (c->order_hint && !capturing) ? c->d_hint_iters : nullptr;
+  // (selective warm start without usable counts -- hint off, captured call: the kernel compares the count array against a
+  //  threshold nobody reaches, so it needs the array; the counts it leaves there are not used while the hint is off)
+  if (c->ws && c->ws_min_iters > 0 && !P.hint_iters) P.hint_iters = c->d_hint_iters;
   P.cu_slots = c->d_cu_slots;
   P.bal_debug = c->bal_debug;
 

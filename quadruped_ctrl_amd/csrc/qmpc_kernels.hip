@@ -1568,13 +1568,18 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     // by itself, the update A - F' C'^T leaves F in the pivot columns by itself, and the publishing thread subtracts 2 from the
     // pivot block's two diagonal entries (2 I - P^-1 -> -P^-1).  No pivot-row branch, no pivot-column write-back.
     if (c == 0) {
-      const double pm0 = (i == 0) ? 1.0 : 0.0, pm1 = (i == 1) ? 1.0 : 0.0;
-      Sw.colbuf[0][0][i] = a[0] - pm0;
-      Sw.colbuf[0][1][i] = a[1] - pm1;
+      Sw.colbuf[0][0][i] = a[0];
+      Sw.colbuf[0][1][i] = a[1];
       const double e_n = lane_next(a[0]), d1_n = lane_next(a[1]);
-      if (i == 0) publish_pinv(a[0], e_n, d1_n, 0);
-      a[0] = __builtin_fma(-2.0, pm0, a[0]);
-      a[1] = __builtin_fma(-2.0, pm1, a[1]);
+      if (i == 0) {
+        publish_pinv(a[0], e_n, d1_n, 0);
+        Sw.colbuf[0][0][i] = a[0] - 1.0;
+        a[0] -= 2.0;
+      }
+      if (i == 1) {
+        Sw.colbuf[0][1][i] = a[1] - 1.0;
+        a[1] -= 2.0;
+      }
     }
     __syncthreads();
 #pragma unroll 1
@@ -1634,13 +1639,23 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           QMPC_STEP_TICK(2, a[rn0] + a[rn1]);
           const int kbn = (r0 + 2 < CW) ? kb : kb + 1;
           if (k0 + 2 < n && c == kbn) {
-            const double pm0 = (i == k0 + 2) ? 1.0 : 0.0, pm1 = (i == k0 + 3) ? 1.0 : 0.0;
-            Sw.colbuf[(m + 1) & 1][0][i] = a[rn0] - pm0;  // C'
-            Sw.colbuf[(m + 1) & 1][1][i] = a[rn1] - pm1;
+            // C' = C - [e_k0' e_k1']: every thread stores its entries of the two columns as they are; the two threads that hold
+            // the pivot block's diagonal store theirs again with 1 subtracted (same lane, same address: LDS keeps a wave's
+            // stores in order) and take 2 off their own copy (2 I - P^-1 -> -P^-1).  Branches, not masks: the 96-row class
+            // has no register to spare here, and only one wave takes them
+            Sw.colbuf[(m + 1) & 1][0][i] = a[rn0];
+            Sw.colbuf[(m + 1) & 1][1][i] = a[rn1];
             const double e_n = lane_next(a[rn0]), d1_n = lane_next(a[rn1]);  // A[k1'][k0'], A[k1'][k1'] of the next pair
-            if (i == k0 + 2) publish_pinv(a[rn0], e_n, d1_n, (m + 1) & 1);
-            a[rn0] = __builtin_fma(-2.0, pm0, a[rn0]);  // the pivot block's diagonal: 2 I - P^-1 -> -P^-1
-            a[rn1] = __builtin_fma(-2.0, pm1, a[rn1]);
+            if (i == k0 + 2) {
+              publish_pinv(a[rn0], e_n, d1_n, (m + 1) & 1);
+              Sw.colbuf[(m + 1) & 1][0][i] = a[rn0] - 1.0;
+              a[rn0] -= 2.0;
+            }
+            if (i == k0 + 3) {
+              asm volatile("" ::: "memory");  // (keeps the block a branch)
+              Sw.colbuf[(m + 1) & 1][1][i] = a[rn1] - 1.0;
+              a[rn1] -= 2.0;
+            }
           }
           QMPC_STEP_TICK(3, 0.0);
           __builtin_amdgcn_sched_barrier(0);
@@ -2140,7 +2155,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // (selective: a robot the previous call found easy starts cold -- a cold dual active set needs ~|W*| iterations
       //  anyway, and a wrong guess costs two events; wave-uniform scalar load)
       bool ws_take = WARM && P.ws != nullptr;
-      if (WARM && ws_take && P.ws_min_iters > 0 && P.hint_iters) ws_take = P.hint_iters[rid] >= P.ws_min_iters;
+      if (WARM && ws_take && P.ws_min_iters > 0) ws_take = P.hint_iters != nullptr && P.hint_iters[rid] >= P.ws_min_iters;
       if (WARM && ws_take && lane < (KS < QMPC_WS_STRIDE ? KS : QMPC_WS_STRIDE)) {
         const int eg = P.ws[(size_t)rid * QMPC_WS_STRIDE + lane];  // global id 5 * (4 step + foot) + type
         const int kg = (eg >= 0 ? eg / 5 : 0) - 4 * P.ws_shift;
