@@ -145,7 +145,7 @@ struct qmpc_ctx {
   int max_iter = 1000;
   double tol = 1e-9;
   float leg_geom[4] = {0.062f, 0.209f, 0.195f, 0.004f};  // MiniCheetah.h:31-37 (abad, hip, knee, knee Y offset)
-  double* d_tables = nullptr;  // coef[3][H] then ctab[9][H][H]
+  double* d_tables = nullptr;  // coef[3][H] then ctab[9][H + 1][H + 1] (zero last row and column: the kernels' identity padding reads them)
   int* d_lists = nullptr;      // [4][max_batch] robot ids handed to classes 4, 2 and 3, and to the large-problem producer
   int* d_counts = nullptr;     // [3 sets][QMPC_COUNTERS] (layout in qmpc_device.h); sets 0 / 1 ping-ponged between calls, set 2: calls captured into a graph
   // decoupled path (sweep kernel -> work items -> engine kernel) of the 128- and 192-row classes: [0] class 2, [1] class 3
@@ -283,7 +283,7 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   c->max_horizon = max_horizon;
   DeviceGuard g(device_id);
   const size_t H = (size_t)max_horizon;
-  hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * H * H));
+  hipError_t e = hipMalloc(&c->d_tables, sizeof(double) * (3 * H + 9 * (H + 1) * (H + 1)));
   if (e == hipSuccess) e = hipMalloc(&c->d_lists, sizeof(int) * 4 * (size_t)max_batch);  // ([3]: the large problems, horizons > 16)
   if (e == hipSuccess) e = hipMalloc(&c->d_counts, sizeof(int) * 3 * QMPC_COUNTERS);
   if (e == hipSuccess) e = hipMemset(c->d_counts, 0, sizeof(int) * 3 * QMPC_COUNTERS);
@@ -390,7 +390,8 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
   if (c->is_setup && c->tab_dt == c->dt && c->tab_h == h && c->tab_model == c->model) return ensure_pools(c);
   // coefficient tables (see qmpc_device.h); A_ct^3 = 0 makes
   // Adt^d Bdt = dt B + c_d A B + e_d A^2 B exact.
-  std::vector<double> t(3 * h + 9 * h * h);
+  const int hs = h + 1;  // row stride of the C_pq tables: row h and column h stay zero
+  std::vector<double> t(3 * h + 9 * hs * hs, 0.0);
   double* coef = t.data();
   double* ctab = t.data() + 3 * h;
   const double d1 = c->dt;
@@ -412,7 +413,7 @@ int qmpc_setup(qmpc_handle c, double dt, int horizon, double mu, double f_max) {
         for (int j = 0; j < h; ++j) {
           double s = 0.0;
           for (int k = (i > j ? i : j); k < h; ++k) s += coef[p * h + (k - i)] * coef[q * h + (k - j)];
-          ctab[((p * 3 + q) * h + i) * h + j] = s;
+          ctab[((p * 3 + q) * hs + i) * hs + j] = s;
         }
   DeviceGuard g(c->device);
   // solves still in flight read the old tables: wait for the stream that orders this handle

@@ -97,7 +97,8 @@ struct QmpcParams {
   int model;
   // batch-constant tables built at qmpc_setup():
   //   coef[p][d]   p<3, d<h     dt, (2d+1)dt^2/2, ((d+1)^3-d^3)dt^3/6
-  //   ctab[pq][i][j] pq<9       sum_{k>=max(i,j)} coef_p(k-i) coef_q(k-j)
+  //   ctab[pq][i][j] pq<9       sum_{k>=max(i,j)} coef_p(k-i) coef_q(k-j), stored (h + 1) x (h + 1) with a ZERO last row and
+  //                             column: rows / columns of the kernels' identity padding index them and vanish by themselves
   const double* coef;
   const double* ctab;
   // solver settings

@@ -278,8 +278,11 @@ struct Smem {
         double Mb[4][9];  // M_b = I_world^-1 [r_b]x                 (B0 rows 6..8)
         double Nb[4][9];  // N_b = R_yaw^T M_b                       (B1 rows 0..2)
         double W[12];
-        double ct0[C::HMAX * C::HMAX], ct4[C::HMAX * C::HMAX];  // C_00 (tau), C_11 (sigma)
-        double ct1[C::HMAX * C::HMAX], ct5[C::HMAX * C::HMAX], ct8[C::HMAX * C::HMAX];  // C_01, C_12, C_22 (x_drag != 0 only)
+        // coefficient tables, (h + 1) x (h + 1) with a ZERO last row and column (built by qmpc_setup): a row of the identity
+        // padding reads row h, a column beyond the stance list column h, and their entries of H vanish by themselves
+        static constexpr int TAB = (C::HMAX + 1) * (C::HMAX + 1);
+        double ct0[TAB], ct4[TAB];  // C_00 (tau), C_11 (sigma)
+        double ct1[TAB], ct5[TAB], ct8[TAB];  // C_01, C_12, C_22 (x_drag != 0 only)
         double E00[144], E11[144];
         double e[C::HMAX * 12];
         double s[3][C::HMAX * 12];
@@ -430,7 +433,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   const bool e_thr = eidx0 < 12 * h;
   const int ek = eidx0 / 12, erow = eidx0 - 12 * ek;
   const int mt = tid % 36, mb = mt / 9, ml = (mt % 9) / 3, max_ = mt % 3;  // (foot, row, axis) of M_b / N_b
-  const int hh = h * h;
+  const int hs = h + 1, hh = hs * hs;  // the tables' row stride and size (zero last row / column)
   // ---- loads.  Command mode (qmpc_solve_commands): the record is generated here from the
   // controller command with the arithmetic of qmpc_cmd.h instead of being loaded.
   constexpr bool cmdm = CMD;  // compile-time: the record path carries no trace of the command mode
@@ -520,8 +523,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   //  for by barrier 2)
   float g_alpha = cmdm ? 4e-5f : PK.alpha[(size_t)rid * PK.alpha_stride];  // ConvexMPCLocomotion.cpp:604
   double g_ct0 = 0.0, g_ct4 = 0.0, g_ct1 = 0.0, g_ct5 = 0.0, g_ct8 = 0.0;
-  // (h * h <= 256 == NT in the 64-row class; the 192-row class -- 768 threads, h * h up to 1296 -- takes a second entry)
-  constexpr bool TAB2 = HMAX * HMAX > NT;
+  // ((h + 1)^2 <= 256 == NT in the 64-row class up to h = 15; h = 16 there, and the 192-row class -- 768 threads, up to 37 x 37
+  //  entries -- take a second entry)
+  constexpr bool TAB2 = (HMAX + 1) * (HMAX + 1) > NT;
   double g2_ct0 = 0.0, g2_ct4 = 0.0, g2_ct1 = 0.0, g2_ct5 = 0.0, g2_ct8 = 0.0;
   if constexpr (TAB2) {
     if (tid + NT < hh) {
@@ -891,7 +895,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         const int ki = S.sidx[r / 3], ai = r % 3, si = ki >> 2, u = 3 * (ki & 3) + ai;
         for (int j = lane; j < n; j += 64) {
           const int kj = S.sidx[j / 3], cax = j % 3, sj = kj >> 2;
-          const int cidx = si * h + sj, tidx = sj * h + si, eidx = u * 12 + 3 * (kj & 3) + cax;
+          const int cidx = si * hs + sj, tidx = sj * hs + si, eidx = u * 12 + 3 * (kj & 3) + cax;
           double v = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
           if (drag) {
             double add = 0.0;
@@ -1263,7 +1267,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     const bool rowok = i < n;
     const int ki = rowok ? (int)S.sidx[(i / 3) & 63] : 0;  // (i/3 < 64 always; the load is unconditional)
     const int ai = rowok ? i % 3 : 0;
-    const int si = ki >> 2;
+    const int si = rowok ? (ki >> 2) : h;  // (identity padding: the tables' zero row)
     const int u = 3 * (ki & 3) + ai;
     const double dm2 = x_drag * inv_m * inv_m;
     // JCQP alternate: A^T R A is DIAGONAL for the friction block (its columns are orthogonal):
@@ -1290,7 +1294,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         for (int b = 0; b < 4; ++b) {
           const int sl = cslot0 + 4 * q4 + b;
           const unsigned kv = S.sidx[sl < 63 ? sl : 63];
-          w |= ((sl < nst) ? kv : 0u) << (8 * b);
+          w |= ((sl < nst) ? kv : (unsigned)(4 * h)) << (8 * b);  // (beyond the stance list: the tables' zero column)
         }
         kjs[q4] = (int)w;
       }
@@ -1299,7 +1303,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       for (int q = 0; q < NSL; ++q) {  // unconditional (clamped) loads: all in flight together
         const int sl = cslot0 + q;
         const int kv = (int)S.sidx[sl < 63 ? sl : 63];
-        kjs[q] = (sl < nst) ? kv : 0;
+        kjs[q] = (sl < nst) ? kv : 4 * h;  // (beyond the stance list: the tables' zero column)
       }
     }
     auto kj_at = [&](int q) __attribute__((always_inline)) {  // q is a compile-time constant at every call site
@@ -1316,7 +1320,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) {
           const int kj = kj_at((CAX0 + jj) / 3), cax = (CAX0 + jj) % 3;
-          const int cidx = si * h + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + cax;
+          const int cidx = si * hs + (kj >> 2), eidx = u * 12 + 3 * (kj & 3) + cax;
           // H = 2 (tau (x) E_00 + sigma (x) E_11 + x_drag terms + alpha I), SolverMPC.cpp:395
           a[jj] = Aa.ct0[cidx] * Aa.E00[eidx] + Aa.ct4[cidx] * Aa.E11[eidx];
           if ((jj & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (VGPR pressure)
@@ -1329,7 +1333,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
         double t0[NS], t4[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-          const int cidx = si * h + (kj_at(q) >> 2);
+          // (identity padding: row h / column h of the tables are zero, so the products of a row beyond n_r or of a slot
+          //  beyond the stance list vanish by themselves -- no compare and no select per element at the end)
+          const int cidx = si * hs + (kj_at(q) >> 2);
           t0[q] = Aa.ct0[cidx];
           t4[q] = Aa.ct4[cidx];
         }
@@ -1353,7 +1359,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj) {
           const int kj = kj_at((CAX0 + jj) / 3), cax = (CAX0 + jj) % 3;
-          const int sj = kj >> 2, cidx = si * h + sj, tidx = sj * h + si;
+          const int sj = kj >> 2, cidx = si * hs + sj, tidx = sj * hs + si;
           double add = 0.0;
           if (ai == 2 && cax == 0) add = Aa.ct1[cidx] * w11 + Aa.ct5[cidx] * w5;
           if (ai == 0 && cax == 2) add = Aa.ct1[tidx] * w11 + Aa.ct5[tidx] * w5;
@@ -1366,12 +1372,26 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     if (cax0 == 0) fill(std::integral_constant<int, 0>{});
     else if (cax0 == 1) fill(std::integral_constant<int, 1>{});
     else fill(std::integral_constant<int, 2>{});
+    if constexpr (RB != 3) {
+      // the padding entries are exact zeros already; its diagonal gets 2 (0 + 1/2) = 1, the real rows' 2 (a + alpha): one
+      // compare, one select and two operations per element (same expression as before on every real entry: same bits)
+      const int dd = i - c * CW;
+      const double dval = rowok ? alpha : 0.5;
+      const double dadm = (ADMM && rowok) ? admm_diag : 0.0;
 #pragma unroll
-    for (int jj = 0; jj < CW; ++jj) {
-      const int j = c * CW + jj;
-      double v = 2.0 * (a[jj] + ((i == j) ? alpha : 0.0));
-      if constexpr (ADMM) v += (i == j) ? admm_diag : 0.0;  // the KKT matrix reduced to the x block
-      a[jj] = (rowok && j < n) ? v : ((i == j) ? 1.0 : 0.0);  // identity padding
+      for (int jj = 0; jj < CW; ++jj) {
+        double v = 2.0 * (a[jj] + ((dd == jj) ? dval : 0.0));
+        if constexpr (ADMM) v += (dd == jj) ? dadm : 0.0;  // the KKT matrix reduced to the x block
+        a[jj] = v;
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < CW; ++jj) {
+        const int j = c * CW + jj;
+        double v = 2.0 * (a[jj] + ((i == j) ? alpha : 0.0));
+        if constexpr (ADMM) v += (i == j) ? admm_diag : 0.0;  // the KKT matrix reduced to the x block
+        a[jj] = (rowok && j < n) ? v : ((i == j) ? 1.0 : 0.0);  // identity padding
+      }
     }
   }
   if (P.dbg_H) {
