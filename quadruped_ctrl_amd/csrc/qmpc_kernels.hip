@@ -803,7 +803,42 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   //   S2[st] = S2[st+1] + 2 S1[st+1] + S0[st+1],  S1[st] = S1[st+1] + S0[st+1],  S0[st] = S0[st+1] + e_st
   // -- O(h) work on twelve threads of wave 3, concurrent with E_00 / E_11 on waves 0-2,
   // instead of O(h^2) LDS-bound dot products on every thread.
-  if (tid >= 192 && tid < 204) {
+  if constexpr (HMAX <= 16) {
+    // (round 6) The same three moments as SUFFIX SCANS inside 16-lane rows: state row r = one DPP row, lane = horizon step.
+    //   S0 = suffix sum of e;  S1[st] = sum_{j > st} S0[j];  T[st] = sum_{j > st} S1[j] = sum_k C(k - st, 2) e_k;  S2 = 2 T + S1
+    // -- four shift-and-add steps per scan (row_shl with zeros shifted in) on 192 threads instead of a 16-step dependent
+    // recurrence on 12: the stage was as long as that chain (3.9 k cycles for 330 vector instructions).  Summation order
+    // differs from the recurrence's: g changes in the last bits (1e-16 relative).
+    if (tid >= 64 && tid < 256) {
+      const int row = (tid - 64) >> 4, st = tid & 15;
+      auto shl = [](double x, auto nc) __attribute__((always_inline)) {  // value of lane + N of this 16-lane row, 0 beyond it
+        constexpr int N = decltype(nc)::value;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x100 + N, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x100 + N, 0xf, 0xf, true);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      };
+      auto suffix = [&](double x) __attribute__((always_inline)) {
+        x += shl(x, std::integral_constant<int, 1>{});
+        x += shl(x, std::integral_constant<int, 2>{});
+        x += shl(x, std::integral_constant<int, 4>{});
+        x += shl(x, std::integral_constant<int, 8>{});
+        return x;
+      };
+      const double e = (st < h) ? Aa.e[st * 12 + row] : 0.0;
+      const double S0 = suffix(e);
+      const double S1 = suffix(shl(S0, std::integral_constant<int, 1>{}));
+      const double T2 = suffix(shl(S1, std::integral_constant<int, 1>{}));
+      const double S2 = 2.0 * T2 + S1;
+      const double dt1 = P.dt, dt2 = dt1 * dt1, dt3 = dt2 * dt1;
+      if (st < h) {
+        Aa.s[0][st * 12 + row] = dt1 * S0;
+        // coef_1(d) = (2d + 1) dt^2 / 2 (exact zero-order hold) or d dt^2 (SparseCMPC: B_d = B dt, c2d)
+        Aa.s[1][st * 12 + row] = (P.model == 1) ? dt2 * S1 : dt2 * S1 + (0.5 * dt2) * S0;
+        Aa.s[2][st * 12 + row] = (0.5 * dt3) * (S2 + S1) + (dt3 / 6.0) * S0;
+      }
+    }
+  } else if (tid >= 192 && tid < 204) {
     const int row = tid - 192;
     double ek[HMAX];
 #pragma unroll
