@@ -62,6 +62,9 @@ namespace {
 #ifndef QMPC_START_PRIO
 #define QMPC_START_PRIO 1
 #endif
+#ifndef QMPC_PROD_PRIO
+#define QMPC_PROD_PRIO 0  // 1: the wave that produces the next pivot pair runs at the highest issue priority while it does (measured, round 6)
+#endif
 
 // a[j] += c[lane j of this lane's row of 16] * u for j = 0..15: sixteen DP-ALU DPP
 // fmacs (row_newbcast), i.e. the 16 wave-uniform pivot-column values are held one
@@ -1551,6 +1554,9 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
           if (k0 + 2 < n && c == kbn) {
             // this wave owns the next pivot pair: its two columns first, then the
             // pivot-block inverse interleaved with the other twelve columns
+#if QMPC_PROD_PRIO
+            __builtin_amdgcn_s_setprio(3);  // (experiment: the producing wave's stream paces the pair)
+#endif
             fmac4_rowbcast<G0>(a, cv0, nu0);
             fmac4_rowbcast<G0>(a, cv1, nu1);
             QMPC_PIN;
@@ -1581,6 +1587,12 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             prod_store(m + 1);
             QMPC_PIN;
             fmac4_rowbcast<G3>(a, cv1, nu1);
+#if QMPC_PROD_PRIO
+            if (hard || (kb == 0 && PK.hint_hard <= 0)) __builtin_amdgcn_s_setprio(3);
+            else if (kb <= 1 || hfloor >= 2) __builtin_amdgcn_s_setprio(2);
+            else if (kb == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
           } else if (c * CW < n) {
             // (a column group that lies entirely in the identity padding never changes:
             //  its pivot-column entries are zero)

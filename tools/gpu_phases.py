@@ -9,7 +9,11 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 # "1".."4" = BASELINE configs; "s10" / "s14" / "s16" = standing at that horizon; "c10".. = calm standing
 b = (W.make_standing(B, int(cfg[1:]), calm=(cfg[0] == "c")) if cfg[0] in "sc" else W.make_config(int(cfg), batch=B))
 mpc = BatchedConvexMPC(0, max_batch=B, max_horizon=16)
+if not os.environ.get("QMPC_PHASE_NO_HINT"):   # (the caller's stance bounds, as bench.py gives them: they select the instantiation)
+    mpc.set_max_stance(int((b["gait"] != 0).sum(1).max()))
+    mpc.set_min_stance(int((b["gait"] != 0).sum(1).min()))
 mpc.setup(b["dt"], b["horizon"], b["mu"], b["f_max"])
+mpc.set_order_hint(0)
 d = mpc.upload(b); o = mpc.alloc_outputs(B); inp, out = mpc.make_args(d, o)
 for _ in range(3): mpc.solve_async(B, inp, out)
 torch.cuda.synchronize()

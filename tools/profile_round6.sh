@@ -43,6 +43,8 @@ for b in 4096 16384; do python $R/bench.py --steps 100 --batch $b --no-cpu-basel
 python $R/bench.py --steps 200 --model sparse > $OUT/bench_sparse_cfg1.json 2> $OUT/bench_sparse_cfg1.err
 python $R/bench.py --steps 100 --model sparse --config 2 --no-closed-loop > $OUT/bench_sparse_cfg2.json 2> $OUT/bench_sparse_cfg2.err
 python $R/tools/shim_latency.py > $OUT/shim_latency.json 2> $OUT/shim_latency.err
+# per-stage shader-clock stamps (one stamped call each): one-round launch, the five-per-CU instantiation, the 96-row class
+(python $R/tools/gpu_phases.py 1 1024; python $R/tools/gpu_phases.py 1 64; python $R/tools/gpu_phases.py 1 8192; python $R/tools/gpu_phases.py 2 4096; python $R/tools/gpu_phases.py 3 4096) > $OUT/phases.txt 2>&1
 cp $R/profiles/pmc_latest.json $OUT/pmc_latest.json
 if [ -f $R/variants/stop4/libqmpc.so ]; then bash $R/tools/census.sh $TAG/census > $OUT/census.log 2>&1; cp $OUT/census/census_table.md $OUT/census_table.md 2>/dev/null; fi
 ls -la $OUT
