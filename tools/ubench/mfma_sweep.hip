@@ -344,6 +344,158 @@ __global__ __launch_bounds__(256, 5) void sweep_a2(long long* clk, double* out, 
 }
 
 
+// ------------------------------------------------------------------ A3: A2 with ROTATING producers and deferred bulk updates
+// Column pair m = (2m, 2m+1) belongs to wave m % 4 (registers 2 (m / 4), +1): the producing role moves to the next wave every
+// pair.  The wave that produces pair s applies pair s - 1's update only to the block of four registers that holds its new pivot
+// columns (8 fmacs) next to the pivot arithmetic and DEFERS the other three blocks, one to each of its next three steps (the
+// updates are additive and commute; a column is complete again long before it becomes a pivot, four pairs later).  Every wave
+// then issues ~40 vector instructions per step (32 + 8 deferred, or 8 + the pivot arithmetic) where the block mapping has
+// 58 in the producer and 36 in the others -- and a step is as long as its longest wave.  Pivot columns and F live in a ring of
+// five step slots (a deferred block reads the pair of four steps ago).
+constexpr int RING = 5;
+struct SmemA3 {
+  alignas(16) double colbuf[RING][2][NP + 2];
+  double ubuf[RING][2][NP];
+  double Hp[NP * (NP + 1) / 2];
+  char pad[LDS_PAD - (RING * 2 * (NP + 2) + RING * 2 * NP + NP * (NP + 1) / 2) * 8];
+};
+// (every control path "defines" all sixteen accumulators, or the register coalescer keeps two copies of the array and moves all
+//  of it at every join)
+__device__ __forceinline__ void touch16(double (&a)[16]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+template <int B>
+__device__ __forceinline__ void fmac_block(double (&a)[16], double c0, double u0, double c1, double u1) {
+  fmac4_rowbcast<4 * B>(a, c0, u0);
+  fmac4_rowbcast<4 * B>(a, c1, u1);
+}
+__device__ __forceinline__ void fmac_block_rt(int b, double (&a)[16], double c0, double u0, double c1, double u1) {
+  if (b == 0) fmac_block<0>(a, c0, u0, c1, u1);
+  else if (b == 1) fmac_block<1>(a, c0, u0, c1, u1);
+  else if (b == 2) fmac_block<2>(a, c0, u0, c1, u1);
+  else fmac_block<3>(a, c0, u0, c1, u1);
+}
+
+__global__ __launch_bounds__(256, 5) void sweep_a3(long long* clk, double* out, int n, int nout) {
+  __shared__ SmemA3 S;
+  const int tid = threadIdx.x, lane = tid & 63, i = tid % NP;
+  const int c = __builtin_amdgcn_readfirstlane(tid / NP);
+  const int seed = blockIdx.x & 1023;
+  auto col = [&](int r) __attribute__((always_inline)) { return 8 * (r >> 1) + 2 * c + (r & 1); };
+  double a[CW];
+#pragma unroll
+  for (int r = 0; r < CW; ++r) a[r] = hmat(i, col(r), n, seed);
+  if (tid == 0) S.pad[0] = 0;
+  __syncthreads();
+  const long long t0 = clock64();
+  bool notpd = false;
+  const int M = (n + 1) >> 1;          // pivot pairs
+  const int mycol = col(lane & 15);    // the column whose pivot-column entry this lane holds for the broadcast
+  double pd0, pe, pd1, pdet, px, pc0, pc1, pm0, pm1, pt0, pt1, pnf0, pnf1;
+  auto prod_read = [&](double c0n, double c1n, int k0n) __attribute__((always_inline)) {
+    pd0 = readlane_f64(c0n, k0n);
+    pe = readlane_f64(c0n, k0n + 1);
+    pd1 = readlane_f64(c1n, k0n + 1);
+    pm0 = (i == k0n) ? 1.0 : 0.0;
+    pm1 = (i == k0n + 1) ? 1.0 : 0.0;
+    pc0 = c0n - pm0;
+    pc1 = c1n - pm1;
+  };
+  auto prod_math = [&]() __attribute__((always_inline)) {
+    pdet = __builtin_fma(pd0, pd1, -pe * pe);
+    notpd |= !(pd0 > 0.0) | !(pdet > 0.0);
+    px = __builtin_amdgcn_rcp(pdet);
+    pt0 = __builtin_fma(pe, pc1, -pd1 * pc0);
+    pt1 = __builtin_fma(pe, pc0, -pd0 * pc1);
+    double e1 = __builtin_fma(-pdet, px, 1.0);
+    px = __builtin_fma(px, e1, px);
+    e1 = __builtin_fma(-pdet, px, 1.0);
+    px = __builtin_fma(px, e1, px);
+    pnf0 = pt0 * px;
+    pnf1 = pt1 * px;
+  };
+  auto prod_store = [&](int slot) __attribute__((always_inline)) {
+    S.colbuf[slot][0][i] = pc0;
+    S.colbuf[slot][1][i] = pc1;
+    S.ubuf[slot][0][i] = pnf0;
+    S.ubuf[slot][1][i] = pnf1;
+  };
+  // steps s = 0 .. M + 3.  Every wave runs ITS OWN straight-line program (role = wave index, known at compile time inside the
+  // program): no branch on the role inside a step, so the sixteen accumulators keep their registers from step to step.
+  auto program = [&](auto rolec) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(rolec)::value;
+    StaticFor<0, 36>::run([&](auto sc) __attribute__((always_inline)) {
+      constexpr int sst = decltype(sc)::value;
+      constexpr int Q = sst >> 2, w = sst & 3;
+      constexpr int PB = (Q >> 1) & 3, DB = w;
+      constexpr int t = (w - ROLE) & 3;
+      if (sst <= M + 3) {
+        const bool have = sst >= 1 && sst - 1 < M;
+        constexpr int slot_p = ((sst - 1) % RING + RING) % RING;
+        double cv0 = 0.0, cv1 = 0.0, nu0 = 0.0, nu1 = 0.0;
+        if (have) {
+          cv0 = S.colbuf[slot_p][0][mycol];
+          cv1 = S.colbuf[slot_p][1][mycol];
+          nu0 = S.ubuf[slot_p][0][i];
+          nu1 = S.ubuf[slot_p][1][i];
+        }
+        if constexpr (t == 0) {
+          if constexpr (Q < 8) {
+            fmac_block<PB>(a, cv0, nu0, cv1, nu1);
+            if constexpr (DB != PB) fmac_block<DB>(a, cv0, nu0, cv1, nu1);
+            // (beyond the last pair this runs on identity padding rows: harmless, nothing of it is read)
+            prod_read(a[2 * Q], a[2 * Q + 1], 2 * sst);
+            a[2 * Q] = __builtin_fma(-2.0, pm0, a[2 * Q]);
+            a[2 * Q + 1] = __builtin_fma(-2.0, pm1, a[2 * Q + 1]);
+            const bool np0 = notpd;
+            prod_math();
+            if (sst >= M) notpd = np0;
+            prod_store(sst % RING);
+          }
+        } else {
+          fmac_block<0>(a, cv0, nu0, cv1, nu1);
+          fmac_block<1>(a, cv0, nu0, cv1, nu1);
+          fmac_block<2>(a, cv0, nu0, cv1, nu1);
+          fmac_block<3>(a, cv0, nu0, cv1, nu1);
+          constexpr int s_mine = sst - t, pd = s_mine - 1;
+          if constexpr (s_mine >= 0 && pd >= 0 && (((s_mine >> 3) & 3) != DB)) {
+            constexpr int slot_d = pd % RING;
+            double dv0 = 0.0, dv1 = 0.0, du0 = 0.0, du1 = 0.0;
+            if (pd < M) {
+              dv0 = S.colbuf[slot_d][0][mycol];
+              dv1 = S.colbuf[slot_d][1][mycol];
+              du0 = S.ubuf[slot_d][0][i];
+              du1 = S.ubuf[slot_d][1][i];
+            }
+            fmac_block<DB>(a, dv0, du0, dv1, du1);
+          }
+        }
+        if (sst <= M) __syncthreads();
+      }
+    });
+  };
+  if (c == 0) program(std::integral_constant<int, 0>{});
+  else if (c == 1) program(std::integral_constant<int, 1>{});
+  else if (c == 2) program(std::integral_constant<int, 2>{});
+  else program(std::integral_constant<int, 3>{});
+  __syncthreads();
+  if (i < n) {
+    const int rb = i * (i + 1) / 2;
+#pragma unroll
+    for (int r = 0; r < CW; ++r) {
+      const int j = col(r);
+      if (j <= i) S.Hp[rb + j] = -a[r];
+    }
+  }
+  __syncthreads();
+  const long long t1 = clock64();
+  if (tid == 0) clk[blockIdx.x] = t1 - t0;
+  if ((int)blockIdx.x < nout)
+    for (int k = tid; k < n * (n + 1) / 2; k += 256) out[(size_t)blockIdx.x * (NP * (NP + 1) / 2) + k] = S.Hp[k];
+  if (__syncthreads_or(notpd ? 1 : 0) && tid == 0) clk[blockIdx.x] = -1;
+}
+
 // ------------------------------------------------------------------ B: tiles on the matrix cores, four pivots per step
 constexpr int TS = 16 * 17;  // a staged tile: column-major with a stride of 17 (conflict-free for writers AND readers)
 struct SmemB {
@@ -804,6 +956,14 @@ int main() {
       double da = 0.0;
       for (size_t k = 0; k < ka.size(); ++k) da = std::max(da, std::fabs(ka[k] - ka2[k]));
       printf("n=%d  max |A - A2| = %.3e\n", n, da);
+    }
+    {
+      std::vector<double> ka3;
+      hipMemset(dout, 0, 8 * 8 * (NP * (NP + 1) / 2));
+      bench("A3:rotate", sweep_a3, n, dclk, dout, &ka3);
+      double da = 0.0;
+      for (size_t k = 0; k < ka.size(); ++k) da = std::max(da, std::fabs(ka[k] - ka3[k]));
+      printf("n=%d  max |A - A3| = %.3e\n", n, da);
     }
     bench("B:mfma", sweep_b<0>, n, dclk, dout, &kb);
     std::vector<double> kc;
