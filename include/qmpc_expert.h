@@ -57,6 +57,17 @@ int qmpc_set_block_start(qmpc_handle h, int on);
  * (its max_batch and stance hints), never of a call's size (since round 5 also for chains with larger classes behind). */
 int qmpc_set_dense(qmpc_handle h, int mode);
 
+/* Size order (default on).  A launch of several rounds of workgroups ends with whichever long robot started last.  When no
+ * order hint is usable (first call, another batch size, qmpc_set_order_hint off) the first size class of the chain takes, from
+ * about 1.5 rounds on, the robots that FIT it largest first by their contact tables (reduced size = 3 x stance foot-steps: the
+ * sweep is that many half-steps long and the smaller problems' iteration counts have the shorter tail), robots it only hands
+ * on keep their place; the permutation is built inside the launch by its first workgroup while the first rounds are solved --
+ * no kernel in front of the call, no host work.  Scheduling only: bit-identical results (tested).  Not used by
+ * one-round launches, handles whose stance hints say every robot has the same size (qmpc_set_min_stance == qmpc_set_max_stance),
+ * command mode (the contact table is generated in the kernel), captured calls, the JCQP alternate, or a contact-table pointer
+ * that is not 8-byte aligned.  on = 0: robot = workgroup index. */
+int qmpc_set_size_order(qmpc_handle h, int on);
+
 /* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for
  * the 128-row class / 192-row class / large problems -- whatever max_batch is; a call with more robots than items runs the
  * class as consecutive chunks (producer kernel, engine kernel, producer kernel, ...) on the caller's stream, the pool reused

@@ -25,7 +25,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
            "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
-           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_order_hint", "qmpc_set_debug_balance",
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_size_order", "qmpc_set_order_hint", "qmpc_set_debug_balance",
            "qmpc_set_warm_start_min_iters", "qmpc_set_debug_overflow_spin"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
@@ -127,6 +127,7 @@ def load_library():
         lib.qmpc_set_debug_engine_events.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_chunks.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_dense.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_set_size_order.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_order_hint.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_debug_balance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_block_start.argtypes = [C.c_void_p, C.c_int]
@@ -515,6 +516,11 @@ class BatchedConvexMPC:
         """0 / 1 / 2: the 64-row class's five-workgroups-per-CU instantiation never / automatic (handles of 2048+ robots; see
         include/qmpc.h) / whenever that class is the whole chain."""
         self._check(self.lib.qmpc_set_dense(self.h, int(mode)), "qmpc_set_dense")
+
+    def set_size_order(self, on):
+        """0 / 1: without a usable order hint, multi-round launches take the robots in blockIdx order / the robots that fit
+        the first class largest first by their contact tables (default; include/qmpc_expert.h)."""
+        self._check(self.lib.qmpc_set_size_order(self.h, int(bool(on))), "qmpc_set_size_order")
 
     def set_order_hint(self, mode):
         """0 / 1: multi-round launches take the robots in blockIdx order / hardest first by the previous call's

@@ -167,6 +167,13 @@ struct qmpc_ctx {
   int order_hint = 1;
   int* d_hint_iters = nullptr;  // [max_batch] iteration counts the one-kernel classes left in the previous call
   int* d_order = nullptr;       // [max_batch] the permutation of this call
+  // size order (qmpc_set_size_order, default on): no hint usable (first call, another batch size, hint off) -> the first class of a
+  // chain, launched over several rounds, takes the robots that fit it largest first by their contact tables; the permutation is
+  // built inside the launch (qmpc_kernels.hip: size_order_build)
+  int size_order = 1;
+  unsigned long long* d_so_order = nullptr;  // [max_batch] (call number << 32 | robot)
+  unsigned so_call = 0;
+  int so_first_pct = 50;
   int hint_batch = 0;           // batch size of the call that wrote d_hint_iters (0: none yet)
   int hint_hard = 5;            // single-round launches: iterations in the previous call from which a robot may keep the highest issue priority (0 = off)
   int* d_hint_max = nullptr;    // [3] largest iteration count of the last calls (slots rotated by hint_call: read / fold / clear)
@@ -291,11 +298,15 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) e = hipMalloc(&c->d_hint_iters, sizeof(int) * (2 * (size_t)max_batch + 4 + 2048));
   if (e == hipSuccess) e = hipMemset(c->d_hint_iters, 0, sizeof(int) * (2 * (size_t)max_batch + 4 + 2048));
   if (e == hipSuccess) c->d_order = c->d_hint_iters + max_batch;
+  if (e == hipSuccess) e = hipMalloc(&c->d_so_order, sizeof(unsigned long long) * 2 * (size_t)max_batch);  // near copy, far copy
+  if (e == hipSuccess) e = hipMemset(c->d_so_order, 0, sizeof(unsigned long long) * 2 * (size_t)max_batch);  // (call numbers start at 1)
   if (e == hipSuccess) c->d_hint_max = c->d_hint_iters + 2 * (size_t)max_batch;
   if (e == hipSuccess) c->d_cu_slots = c->d_hint_max + 4;  // [2048] the 96-row class's per-CU placement words (zero whenever no kernel runs)
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = (ns && ns[0] == '1') ? 0 : 1;
+    const char* sf = std::getenv("QMPC_SO_FIRST_PCT");  // (measurement knob: the unsorted head of a size-ordered launch, % of a round beyond the first)
+    if (sf) c->so_first_pct = std::atoi(sf);
     const char* hh = std::getenv("QMPC_HINT_HARD");
     if (hh) c->hint_hard = std::atoi(hh);
     const char* nb = std::getenv("QMPC_BLOCK");
@@ -347,6 +358,7 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_evflags) hipFree(h->d_evflags);
     if (h->d_fb_lists) hipFree(h->d_fb_lists);
     if (h->d_hint_iters) hipFree(h->d_hint_iters);
+    if (h->d_so_order) hipFree(h->d_so_order);
     for (int k = 0; k < 3; ++k) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
@@ -539,6 +551,12 @@ int qmpc_set_dense(qmpc_handle c, int mode) {
 int qmpc_set_debug_balance(qmpc_handle c, int mode) {
   if (!c || mode < 0 || mode > 2) return QMPC_ERR_ARG;
   c->bal_debug = mode;
+  return QMPC_OK;
+}
+
+int qmpc_set_size_order(qmpc_handle c, int on) {
+  if (!c || on < 0 || on > 1) return QMPC_ERR_ARG;
+  c->size_order = on;
   return QMPC_OK;
 }
 
@@ -1011,7 +1029,33 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         if (c->hint_batch == batch) P.hint_hard = c->hint_hard;
       }
     }
+    // size order: no usable hint, several rounds, the robots' sizes differ (or the caller did not say), contact tables in memory
+    // (record mode) and 8-byte aligned.  The first 1.5 rounds keep robot = workgroup index: the builders (the first workgroups, one
+    // segment of the rest each) need a few microseconds, and the workgroups that follow robots which are only handed on start
+    // within a few microseconds as well
+    P.so_order = nullptr;
+    if (!listed && c->size_order && !capturing && !P.admm_mode && !cmd && !P.order && P.gait &&
+        ((uintptr_t)P.gait & 7u) == 0 && !(c->min_stance > 0 && c->min_stance == c->max_stance)) {
+      const int res = qmpc_resident_blocks(kcls);
+      if (res > 0 && batch > res) {
+        const int head = (int)((long long)res * c->so_first_pct / 100);
+        const int half = (batch - res) / 2 < head ? (batch - res) / 2 : head;
+        P.so_first = (res + half + 7) & ~7;
+        const int n = batch - P.so_first;
+        if (n >= 64) {
+          // strided segments of at most 4096 robots (QMPC_SO_SEG of qmpc_kernels.hip: the builder's LDS scratch)
+          // (a multiple of 8, and so_first too: place b of segment j has b % 8 == j % 8 -- readers and builder on one XCD)
+          P.so_nseg = 8 * ((n + 8 * 4096 - 1) / (8 * 4096));
+          P.so_order = c->d_so_order;
+          P.so_far = c->d_so_order + c->max_batch;
+          P.so_tag = ++c->so_call;
+          if (P.so_tag == 0) P.so_tag = ++c->so_call;  // (0 is what fresh memory holds)
+          P.so_maxfit = kRows[k] / 3;
+        }
+      }
+    }
     HIP_TRY(c, qmpc_launch(kcls, &P, grid, stream));
+    P.so_order = nullptr;
     P.order = nullptr;
     P.hint_hard = 0;
     P.hint_max_z = nullptr;

@@ -208,6 +208,14 @@ struct QmpcParams {
   const int32_t* hint_max_r;
   int32_t* hint_max_w;
   int32_t* hint_max_z;
+  // size order (qmpc_kernels.hip: size_order_build; nullptr = off): in a launch of several rounds the workgroups from so_first on
+  // take robot so_order[blockIdx.x] -- the robots that fit the class largest first (by their contact tables) within so_nseg
+  // strided segments (robot so_first + j + so_nseg t: segment j), segment j built by workgroup j of the same launch; entries are
+  // (so_tag << 32 | robot), so_tag = a per-handle call number
+  unsigned long long* so_order;  // near copy (plain stores: stays in the builder's XCD's L2)
+  unsigned long long* so_far;    // far copy (written through: what a reader polls when the near probe missed)
+  unsigned so_tag;
+  int so_first, so_maxfit, so_nseg;
 };
 
 #endif

@@ -3329,6 +3329,142 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
   }
 }
 
+// SIZE ORDER: a launch of several rounds of workgroups ends with whichever long robot started last.  What a
+// robot will cost is not known before its inverse exists -- except for its reduced size n_r = 3 x stance foot-steps, which
+// is in its contact table: the sweep is n_r / 2 steps long, and the smaller problems' iteration counts have the shorter
+// tail (configs[2]: bounding, 48 rows, at most 17 iterations; trot / pacing, 60 rows, up to 23).  So the workgroups
+// beyond so_first (about 1.5 rounds) take the robots THAT FIT THIS CLASS largest first; a robot the class only hands on
+// keeps its place (bunching those costs more than any order of theirs gives: they hide behind their neighbours' sweeps).
+// The permutation is built INSIDE the launch while the first rounds are being solved -- a sort kernel in front of the launch
+// would cost what the order gives (4 us of 126): the robots from so_first on are dealt to so_nseg segments of at most 4096
+// (robot so_first + j + nseg t belongs to segment j), workgroup j sorts segment j WITHIN itself before it solves its own robot
+// (one workgroup sorting everything took 5 ns per robot, too long from 8192 robots on) with keys, positions and the sorted
+// list in LDS -- the solve's phase-local storage, not in use yet -- and hands the
+// result over through 8-byte entries (call tag << 32 | robot): a workgroup reads its own entry until the tag is this call's.
+// Nobody waits in practice (the first entry is needed ~40 us into the launch, a segment is sorted in well under 10); the wait
+// is bounded all the same, and a workgroup that gives up takes robot = blockIdx.x -- the identity, which is what every reader
+// of the segment gets if its builder never ran.  Results do not depend on the order (a robot is solved by one workgroup from
+// its own record).
+#define QMPC_SO_SEG 4096
+__device__ __forceinline__ int qmpc_count_stance(const uint8_t* __restrict__ g, const int nfs) {
+  // nonzero bytes of the 4 h-byte contact table (4 h is a multiple of 4, the base is 8-byte aligned: the host checks)
+  const uint32_t* g4 = reinterpret_cast<const uint32_t*>(g);
+  int nst = 0;
+  for (int k = 0; k < (nfs >> 2); ++k) {
+    const uint32_t w = g4[k];
+    const uint32_t t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // bit 7 of every nonzero byte
+    nst += __builtin_popcount(t);
+  }
+  return nst;
+}
+template <int RB>
+__device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, const QmpcParams& P) {
+  constexpr int NT = Cfg<RB>::NT, NW = NT / 64;
+  static_assert(sizeof(S.u) >= 64 * 4 + 16 * 4 + QMPC_SO_SEG * 5, "size order: scratch in the phase-local storage");
+  int* hist = reinterpret_cast<int*>(&S.u);  // 64 bins
+  int* wcnt = hist + 64;                     // NW wave totals
+  unsigned char* keys = reinterpret_cast<unsigned char*>(wcnt + 16);               // [seg] bin, 0xff = handed on
+  unsigned short* fitpos = reinterpret_cast<unsigned short*>(keys + QMPC_SO_SEG);  // [seg] positions of the fitting robots, index order
+  unsigned short* sorted = fitpos + QMPC_SO_SEG;                                   // [seg] the fitting robots in bin order
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nfs = 4 * P.horizon, maxfit = P.so_maxfit;
+  // this workgroup's segment: the robots (and places) s0 + nseg t, t < n -- STRIDED, so that every segment is a sample of the
+  // whole batch and the t-th largest robots of all segments land next to each other: the launch as a whole runs from large to
+  // small without the builders exchanging a word
+  const int nseg = P.so_nseg, s0 = P.so_first + (int)blockIdx.x;
+  const int n = (P.batch - s0 + nseg - 1) / nseg;
+  const unsigned long long tag = (unsigned long long)P.so_tag << 32;
+  // an entry is stored TWICE: plainly into the near copy (the line stays in this XCD's L2: workgroup b runs on XCD b % 8 and
+  // so_nseg is a multiple of 8, so a segment's readers sit on its builder's XCD and their one probe is an L2 hit) and written
+  // through (sc1) into the far copy, which is what a reader polls if the near probe did not show this call's tag -- whatever
+  // the placement, a tag that matches was written in this call, and the far copy is the plain tagged-granule hand-off
+  auto so_put = [&](int place, int robot) __attribute__((always_inline)) {
+    const unsigned long long v = tag | (unsigned)robot;
+    P.so_order[place] = v;
+    __hip_atomic_store(P.so_far + place, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  __builtin_amdgcn_s_setprio(3);
+  if (tid < 64 + NW) hist[tid] = 0;
+  __syncthreads();
+  // wave wv: the robots [lo, hi) of the segment, 256 at a time (four per lane: forty loads in flight)
+  const int per = ((n + NW - 1) / NW + 63) & ~63;
+  const int lo = wv * per, hi = (lo + per < n) ? lo + per : n;
+  int nfit = 0;
+  for (int base = lo; base < hi; base += 256) {
+    int key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane;
+      key[u] = -2;
+      if (i < hi) {
+        const int nst = qmpc_count_stance(P.gait + (size_t)(s0 + nseg * i) * nfs, nfs);
+        const int d = maxfit - nst;
+        key[u] = (d < 0) ? -1 : (d > 63 ? 63 : d);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane;
+      if (key[u] > -2) keys[i] = (unsigned char)key[u];
+      if (key[u] >= 0) atomicAdd(&hist[key[u]], 1);
+      nfit += __popcll(__ballot(key[u] >= 0));
+    }
+  }
+  if (lane == 0) wcnt[wv] = nfit;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int cw = wcnt[w];
+    wbase += (w < wv) ? cw : 0;
+    total += cw;
+  }
+  int excl = 0;
+  if (tid < 64) {  // exclusive prefix over the bins: one wave, six shuffle steps
+    const int cnt = hist[tid];
+    int acc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(acc, d);
+      if (tid >= d) acc += up;
+    }
+    excl = acc - cnt;
+  }
+  __syncthreads();  // (everybody has read the wave totals and the counts)
+  if (tid < 64) hist[tid] = excl;
+  __syncthreads();
+  int run = wbase;
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + lane;
+    const int key = (i < hi) ? (int)keys[i] : 0xfe;
+    const bool fit = key < 64;
+    const unsigned long long m = __ballot(fit);
+    if (key == 0xff) so_put(s0 + nseg * i, s0 + nseg * i);  // handed on: keeps its place
+    if (fit) {
+      fitpos[run + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      sorted[atomicAdd(&hist[key], 1)] = (unsigned short)i;
+    }
+    run += __popcll(m);
+  }
+  __syncthreads();
+  for (int k = tid; k < total; k += NT) so_put(s0 + nseg * fitpos[k], s0 + nseg * sorted[k]);
+  __syncthreads();  // (the scratch is the solve's from here on)
+  __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ int size_order_take(const QmpcParams& P) {
+  // one probe of the near copy (bypassing this CU's L1: an L2 hit when the builder ran on this XCD) ...
+  unsigned long long v = __hip_atomic_load(P.so_order + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((unsigned)(v >> 32) == P.so_tag) return __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  // ... then the far copy until it carries this call's tag
+  const unsigned long long* e = P.so_far + blockIdx.x;
+  for (int spin = 0; spin < (1 << 18); ++spin) {  // (bounded: ~1 s)
+    v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(v >> 32) == P.so_tag) return __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    __builtin_amdgcn_s_sleep(32);
+  }
+  return (int)blockIdx.x;
+}
+
 #ifndef QMPC_LISTED_VARIANT
 #define QMPC_LISTED_VARIANT 2
 #endif
@@ -3352,7 +3488,16 @@ __global__ __launch_bounds__(Cfg<RB>::NT_LAUNCH, Cfg<RB>::MIN_WAVES) void qmpc_s
     if (blockIdx.x == 0 && tid0 == 0 && P.hint_max_z) *P.hint_max_z = 0;
     pool_acquire<RB>(S, P);
     // (order hint: the previous call's hardest robots first; results do not depend on the order)
-    const int rid = P.order ? __builtin_amdgcn_readfirstlane(P.order[blockIdx.x]) : (int)blockIdx.x;
+    int rid = P.order ? __builtin_amdgcn_readfirstlane(P.order[blockIdx.x]) : (int)blockIdx.x;
+    if constexpr (!CMD) {
+      // (size order: the first workgroups build the permutation, a segment each, before they solve their own robots; the
+      //  workgroups of the later rounds read it)
+      if (P.so_order) {
+        if ((int)blockIdx.x < P.so_nseg) size_order_build<RB>(tid0, S, P);
+        else if ((int)blockIdx.x >= P.so_first) rid = size_order_take(P);
+      }
+    }
+    __builtin_assume(tid0 >= 0 && tid0 < Cfg<RB>::NT);
     solve_robot<RB, CMD, WARM>(rid, tid0, S, P);
     pool_release<RB>(S, P);
     balance_release<RB>(tid0, S, P);

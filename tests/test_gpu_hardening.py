@@ -304,6 +304,82 @@ def test_order_hint_changes_the_order_not_the_results(mpc_factory):
               f"(exact / stale / after a call of another size)")
 
 
+def _take(b, idx):
+    B = int(b["batch"])
+    o = {k: (v[idx].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in b.items()}
+    o["batch"] = int(len(idx))
+    return o
+
+
+def test_size_order_changes_the_order_not_the_results(mpc_factory):
+    """qmpc_set_size_order (default on): without a usable order hint the first class of a chain, launched over
+    several rounds of workgroups, takes the robots that fit it largest first by their contact tables -- the permutation built
+    inside the launch by its first workgroups, handed over through tagged 8-byte entries.  Scheduling only: forces, solutions,
+    iteration counts and status are bit-identical to robot = workgroup index -- single class (configs[2]), a chain with hand-overs
+    (configs[4], with and without stance hints), a chain that starts at the 96-row class (eight waves launched, six stay),
+    ragged batch sizes, and one handle called with changing batch sizes (entries and tags of earlier calls in the same rows)."""
+    big = W.make_config(4, batch=12000)
+    nst = (big["gait"].reshape(12000, -1) != 0).sum(1)
+    mid = _take(big, np.nonzero((nst >= 22) & (nst <= 32))[0][:3000])  # every robot belongs to the 96-row class
+    cases = ((W.make_config(2, batch=4096), True), (W.make_config(2, batch=3001), False), (W.make_config(4, batch=5000), True),
+             (W.make_config(4, batch=2500), False), (mid, True))
+    for b, stance in cases:
+        B = int(b["batch"])
+        m = mpc_factory(b)
+        if stance:
+            m.set_max_stance(int((b["gait"] != 0).sum(1).max()))
+            m.set_min_stance(int((b["gait"] != 0).sum(1).min()))
+        m.set_order_hint(0)
+        m.set_size_order(0)
+        base = m.solve(b, full=True)
+        assert ((base["status"] & 47) == 0).all()
+        m.set_size_order(1)
+        for rep in range(3):  # (every call has its own tag; the entries of the call before are still in the rows)
+            res = m.solve(b, full=True)
+            for k in ("grf", "soln", "iters", "status"):
+                assert np.array_equal(res[k], base[k]), (k, B, rep)
+        # other batch sizes on the same handle, then the full batch again
+        for nb in (B // 2 + 37, 1500, B - 1, B):
+            part = _take(b, np.arange(nb))
+            res = m.solve(part, full=True)
+            for k in ("grf", "soln", "iters", "status"):
+                assert np.array_equal(res[k], base[k][:nb]), (k, B, nb)
+        # the batch reversed: other robots in the same rows
+        rb = _take(b, np.arange(B)[::-1])
+        res = m.solve(rb, full=True)
+        for k in ("grf", "soln", "iters"):
+            assert np.array_equal(res[k], base[k][::-1]), k
+        # with the hint on: the first call has no counts yet (size order), the second is ordered by them (the hint wins)
+        m.set_order_hint(1)
+        for rep in range(2):
+            res = m.solve(b, full=True)
+            for k in ("grf", "soln", "iters"):
+                assert np.array_equal(res[k], base[k]), (k, "hint", rep)
+        print(f"   size order: B={B} h={b['horizon']} stance hints {stance}: bit-identical (repeated, other batch sizes, reversed, with the hint)")
+
+
+def test_size_order_contact_table_pointer_not_aligned(mpc_factory):
+    """The builder reads the contact tables with 4-byte loads from an 8-byte aligned base; any other pointer switches the size
+    order off for the call (same results, robot = workgroup index)."""
+    import torch
+    b = W.make_config(2, batch=3000)
+    B = int(b["batch"])
+    m = mpc_factory(b)
+    m.set_order_hint(0)
+    base = m.solve(b, full=True)
+    d = m.upload(b)
+    raw = torch.empty(d["gait"].numel() + 8, dtype=torch.uint8, device=d["gait"].device)
+    shifted = raw[3:3 + d["gait"].numel()].view(d["gait"].shape)
+    shifted.copy_(d["gait"])
+    assert shifted.data_ptr() % 8 != 0
+    d["gait"] = shifted
+    o = m.alloc_outputs(B, full=True)
+    inp, out = m.make_args(d, o)
+    m.solve_async(B, inp, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(o["soln"].cpu().numpy(), base["soln"]) and np.array_equal(o["iters"].cpu().numpy(), base["iters"])
+
+
 def test_wave_placement_of_the_96_row_class_does_not_change_results(mpc_factory):
     """The 96-row class's solve kernels are launched with eight waves; six stay, picked by where the hardware put them
     (HW_REG_HW_ID) and by a per-CU slot word so that two co-resident workgroups complement each other.
