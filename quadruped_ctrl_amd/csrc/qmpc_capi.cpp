@@ -174,6 +174,7 @@ struct qmpc_ctx {
   unsigned long long* d_so_order = nullptr;  // [max_batch] (call number << 32 | robot)
   unsigned so_call = 0;
   int so_first_pct = 50;
+  int hint_prepass = 0;  // 1: the order hint's permutation by a sort kernel in front of the call (as until round 6)
   int hint_batch = 0;           // batch size of the call that wrote d_hint_iters (0: none yet)
   int hint_hard = 5;            // single-round launches: iterations in the previous call from which a robot may keep the highest issue priority (0 = off)
   int* d_hint_max = nullptr;    // [3] largest iteration count of the last calls (slots rotated by hint_call: read / fold / clear)
@@ -307,6 +308,8 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
     c->split = (ns && ns[0] == '1') ? 0 : 1;
     const char* sf = std::getenv("QMPC_SO_FIRST_PCT");  // (measurement knob: the unsorted head of a size-ordered launch, % of a round beyond the first)
     if (sf) c->so_first_pct = std::atoi(sf);
+    const char* hp = std::getenv("QMPC_HINT_PREPASS");
+    if (hp) c->hint_prepass = std::atoi(hp);
     const char* hh = std::getenv("QMPC_HINT_HARD");
     if (hh) c->hint_hard = std::atoi(hh);
     const char* nb = std::getenv("QMPC_BLOCK");
@@ -1013,12 +1016,17 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     // (Only there: in a launch of many rounds it costs 3 %, measured at 16384 robots.)
     P.order = nullptr;
     P.hint_hard = 0;
+    bool use_hint_keys = false;
     if (!listed && c->order_hint && !capturing && !P.admm_mode) {
       if (batch > qmpc_resident_blocks(kcls)) {
         if (c->hint_batch == batch) {
-          hipLaunchKernelGGL(qmpc_order_kernel, dim3(1), dim3(1024), 0, stream, (const int*)c->d_hint_iters, c->d_order, batch);
-          HIP_TRY(c, hipGetLastError());
-          P.order = c->d_order;
+          if (c->hint_prepass) {  // (until round 6, kept for comparison: QMPC_HINT_PREPASS=1)
+            hipLaunchKernelGGL(qmpc_order_kernel, dim3(1), dim3(1024), 0, stream, (const int*)c->d_hint_iters, c->d_order, batch);
+            HIP_TRY(c, hipGetLastError());
+            P.order = c->d_order;
+          } else {
+            use_hint_keys = true;  // the permutation is built inside the launch (below), keys = the previous call's counts
+          }
         }
       } else if (2 * batch > qmpc_resident_blocks(kcls)) {  // (workgroups share CUs: below that priority has nobody to act on)
         // the largest count of the previous one-round call / of this one / cleared for the next: three slots in rotation
@@ -1034,23 +1042,26 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
     // segment of the rest each) need a few microseconds, and the workgroups that follow robots which are only handed on start
     // within a few microseconds as well
     P.so_order = nullptr;
-    if (!listed && c->size_order && !capturing && !P.admm_mode && !cmd && !P.order && P.gait &&
-        ((uintptr_t)P.gait & 7u) == 0 && !(c->min_stance > 0 && c->min_stance == c->max_stance)) {
+    const bool by_size = c->size_order && !cmd && P.gait && ((uintptr_t)P.gait & 7u) == 0 &&
+                         !(c->min_stance > 0 && c->min_stance == c->max_stance);
+    if (!listed && !capturing && !P.admm_mode && !P.order && (use_hint_keys || by_size)) {
       const int res = qmpc_resident_blocks(kcls);
       if (res > 0 && batch > res) {
         const int head = (int)((long long)res * c->so_first_pct / 100);
         const int half = (batch - res) / 2 < head ? (batch - res) / 2 : head;
         P.so_first = (res + half + 7) & ~7;
         const int n = batch - P.so_first;
-        if (n >= 64) {
+        if (n >= 64 && 17 * 8 * ((n + 8 * 4080 - 1) / (8 * 4080)) <= P.so_first) {
           // strided segments of at most 4096 robots (QMPC_SO_SEG of qmpc_kernels.hip: the builder's LDS scratch)
           // (a multiple of 8, and so_first too: place b of segment j has b % 8 == j % 8 -- readers and builder on one XCD)
-          P.so_nseg = 8 * ((n + 8 * 4096 - 1) / (8 * 4096));
+          // (QMPC_SO_HEAD = 16 places of the first round per segment on top: 17 nseg workgroups in front of so_first)
+          P.so_nseg = 8 * ((n + 8 * 4080 - 1) / (8 * 4080));
           P.so_order = c->d_so_order;
           P.so_far = c->d_so_order + c->max_batch;
           P.so_tag = ++c->so_call;
           if (P.so_tag == 0) P.so_tag = ++c->so_call;  // (0 is what fresh memory holds)
           P.so_maxfit = kRows[k] / 3;
+          P.so_hint = use_hint_keys ? c->d_hint_iters : nullptr;
         }
       }
     }

@@ -214,6 +214,7 @@ struct QmpcParams {
   // (so_tag << 32 | robot), so_tag = a per-handle call number
   unsigned long long* so_order;  // near copy (plain stores: stays in the builder's XCD's L2)
   unsigned long long* so_far;    // far copy (written through: what a reader polls when the near probe missed)
+  const int32_t* so_hint;        // nullptr: keys from the contact tables; else the previous call's iteration counts (order hint)
   unsigned so_tag;
   int so_first, so_maxfit, so_nseg;
 };

@@ -3346,6 +3346,7 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
 // of the segment gets if its builder never ran.  Results do not depend on the order (a robot is solved by one workgroup from
 // its own record).
 #define QMPC_SO_SEG 4096
+#define QMPC_SO_HEAD 16  // robots / places of the first round per segment (qmpc_capi.cpp sizes the segments: QMPC_SO_SEG - QMPC_SO_HEAD strided robots at most)
 __device__ __forceinline__ int qmpc_count_stance(const uint8_t* __restrict__ g, const int nfs) {
   // nonzero bytes of the 4 h-byte contact table (4 h is a multiple of 4, the base is 8-byte aligned: the host checks)
   const uint32_t* g4 = reinterpret_cast<const uint32_t*>(g);
@@ -3357,7 +3358,10 @@ __device__ __forceinline__ int qmpc_count_stance(const uint8_t* __restrict__ g, 
   }
   return nst;
 }
-template <int RB>
+// The same builder serves the ORDER HINT (so_hint != nullptr: the iteration counts the handle's previous call left, one per
+// robot): key = the count, every robot takes part (a robot that is handed on carries the count of the class that solved it,
+// so the next class's queue comes out hardest first as well) -- in place of a sort kernel in front of the call.
+template <int RB, bool CMD>
 __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, const QmpcParams& P) {
   constexpr int NT = Cfg<RB>::NT, NW = NT / 64;
   static_assert(sizeof(S.u) >= 64 * 4 + 16 * 4 + QMPC_SO_SEG * 5, "size order: scratch in the phase-local storage");
@@ -3372,7 +3376,14 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
   // whole batch and the t-th largest robots of all segments land next to each other: the launch as a whole runs from large to
   // small without the builders exchanging a word
   const int nseg = P.so_nseg, s0 = P.so_first + (int)blockIdx.x;
-  const int n = (P.batch - s0 + nseg - 1) / nseg;
+  // ... preceded by QMPC_SO_HEAD robots (and places) of the launch's FIRST round, nseg + j + nseg t: the workgroups right behind the
+  // builders wait the few microseconds a builder takes and start the segment's largest / hardest robots at once -- a robot that
+  // will iterate thirty times must not start a round and a half into the launch (closed-loop rollouts: a handful of such robots,
+  // mean count 1.6)
+  const int n = QMPC_SO_HEAD + (P.batch - s0 + nseg - 1) / nseg;
+  auto gidx = [&](int t) __attribute__((always_inline)) {
+    return t < QMPC_SO_HEAD ? nseg + (int)blockIdx.x + nseg * t : s0 + nseg * (t - QMPC_SO_HEAD);
+  };
   const unsigned long long tag = (unsigned long long)P.so_tag << 32;
   // an entry is stored TWICE: plainly into the near copy (the line stays in this XCD's L2: workgroup b runs on XCD b % 8 and
   // so_nseg is a multiple of 8, so a segment's readers sit on its builder's XCD and their one probe is an L2 hit) and written
@@ -3397,8 +3408,13 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
       const int i = base + 64 * u + lane;
       key[u] = -2;
       if (i < hi) {
-        const int nst = qmpc_count_stance(P.gait + (size_t)(s0 + nseg * i) * nfs, nfs);
-        const int d = maxfit - nst;
+        int d;
+        if (CMD || P.so_hint) {
+          d = 63 - P.so_hint[gidx(i)];  // (command mode: the contact table exists in registers only -- hint or nothing)
+          d = d < 0 ? 0 : d;
+        } else {
+          d = maxfit - qmpc_count_stance(P.gait + (size_t)gidx(i) * nfs, nfs);
+        }
         key[u] = (d < 0) ? -1 : (d > 63 ? 63 : d);
       }
     }
@@ -3439,7 +3455,7 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
     const int key = (i < hi) ? (int)keys[i] : 0xfe;
     const bool fit = key < 64;
     const unsigned long long m = __ballot(fit);
-    if (key == 0xff) so_put(s0 + nseg * i, s0 + nseg * i);  // handed on: keeps its place
+    if (key == 0xff) so_put(gidx(i), gidx(i));  // handed on: keeps its place
     if (fit) {
       fitpos[run + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
       sorted[atomicAdd(&hist[key], 1)] = (unsigned short)i;
@@ -3447,7 +3463,7 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
     run += __popcll(m);
   }
   __syncthreads();
-  for (int k = tid; k < total; k += NT) so_put(s0 + nseg * fitpos[k], s0 + nseg * sorted[k]);
+  for (int k = tid; k < total; k += NT) so_put(gidx(fitpos[k]), gidx(sorted[k]));
   __syncthreads();  // (the scratch is the solve's from here on)
   __builtin_amdgcn_s_setprio(0);
 }
@@ -3489,13 +3505,11 @@ __global__ __launch_bounds__(Cfg<RB>::NT_LAUNCH, Cfg<RB>::MIN_WAVES) void qmpc_s
     pool_acquire<RB>(S, P);
     // (order hint: the previous call's hardest robots first; results do not depend on the order)
     int rid = P.order ? __builtin_amdgcn_readfirstlane(P.order[blockIdx.x]) : (int)blockIdx.x;
-    if constexpr (!CMD) {
-      // (size order: the first workgroups build the permutation, a segment each, before they solve their own robots; the
-      //  workgroups of the later rounds read it)
-      if (P.so_order) {
-        if ((int)blockIdx.x < P.so_nseg) size_order_build<RB>(tid0, S, P);
-        else if ((int)blockIdx.x >= P.so_first) rid = size_order_take(P);
-      }
+    // (size order / order hint: the first workgroups build the permutation, a segment each, before they solve their own robots;
+    //  the workgroups of the later rounds read it)
+    if (P.so_order) {
+      if ((int)blockIdx.x < P.so_nseg) size_order_build<RB, CMD>(tid0, S, P);
+      else if ((int)blockIdx.x >= P.so_first || (int)blockIdx.x < P.so_nseg * (QMPC_SO_HEAD + 1)) rid = size_order_take(P);
     }
     __builtin_assume(tid0 >= 0 && tid0 < Cfg<RB>::NT);
     solve_robot<RB, CMD, WARM>(rid, tid0, S, P);
