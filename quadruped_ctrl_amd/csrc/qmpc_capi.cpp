@@ -1037,13 +1037,12 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         if (c->hint_batch == batch) P.hint_hard = c->hint_hard;
       }
     }
-    // size order: no usable hint, several rounds, the robots' sizes differ (or the caller did not say), contact tables in memory
-    // (record mode) and 8-byte aligned.  The first 1.5 rounds keep robot = workgroup index: the builders (the first workgroups, one
+    // size order: no usable hint, several rounds, contact tables in memory (record mode) and 8-byte aligned (robots of one size
+    // are ordered by the tracking-error proxy instead: the builder decides).  The first 1.5 rounds keep robot = workgroup index: the builders (the first workgroups, one
     // segment of the rest each) need a few microseconds, and the workgroups that follow robots which are only handed on start
     // within a few microseconds as well
     P.so_order = nullptr;
-    const bool by_size = c->size_order && !cmd && P.gait && ((uintptr_t)P.gait & 7u) == 0 &&
-                         !(c->min_stance > 0 && c->min_stance == c->max_stance);
+    const bool by_size = c->size_order && !cmd && P.gait && ((uintptr_t)P.gait & 7u) == 0;
     if (!listed && !capturing && !P.admm_mode && !P.order && (use_hint_keys || by_size)) {
       const int res = qmpc_resident_blocks(kcls);
       if (res > 0 && batch > res) {

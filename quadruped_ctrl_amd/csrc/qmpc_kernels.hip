@@ -3333,8 +3333,9 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
 // robot will cost is not known before its inverse exists -- except for its reduced size n_r = 3 x stance foot-steps, which
 // is in its contact table: the sweep is n_r / 2 steps long, and the smaller problems' iteration counts have the shorter
 // tail (configs[2]: bounding, 48 rows, at most 17 iterations; trot / pacing, 60 rows, up to 23).  So the workgroups
-// beyond so_first (about 1.5 rounds) take the robots THAT FIT THIS CLASS largest first; a robot the class only hands on
-// keeps its place (bunching those costs more than any order of theirs gives: they hide behind their neighbours' sweeps).
+// beyond so_first (about 1.5 rounds) take the robots THAT FIT THIS CLASS largest first; the robots the class only hands on
+// stay among their own places (bunching those costs more than any order of theirs gives: they hide behind their neighbours'
+// sweeps) and are ordered among themselves for the NEXT class's sake (qmpc_handover_bin below).
 // The permutation is built INSIDE the launch while the first rounds are being solved -- a sort kernel in front of the launch
 // would cost what the order gives (4 us of 126): the robots from so_first on are dealt to so_nseg segments of at most 4096
 // (robot so_first + j + nseg t belongs to segment j), workgroup j sorts segment j WITHIN itself before it solves its own robot
@@ -3361,15 +3362,47 @@ __device__ __forceinline__ int qmpc_count_stance(const uint8_t* __restrict__ g, 
 // The same builder serves the ORDER HINT (so_hint != nullptr: the iteration counts the handle's previous call left, one per
 // robot): key = the count, every robot takes part (a robot that is handed on carries the count of the class that solved it,
 // so the next class's queue comes out hardest first as well) -- in place of a sort kernel in front of the call.
+// A robot this class only HANDS ON is ordered as well -- among the places of the robots handed on, so that nothing bunches: the
+// next class's queue is filled in dispatch order, and that launch (two workgroups per CU, robots that iterate up to forty times)
+// ends with whichever long robot it took last.  Key: the tracking error the COASTING state would have at the end of the horizon,
+// sum_k Q_k |e_k + T de_k| / sum_k Q_k over orientation and position (T = h dt; small-angle roll / pitch: a proxy), times the stance
+// foot-steps of the first three segments -- correlation with the iteration count 0.74 on configs[4]'s robots (0.24 for the size
+// alone), hardest first in 64 logarithmic bins (six per octave).  NOT for the robots that fit: on configs[2] any order by
+// this key is worse than none (3.15e7 against 3.22e7; by size 3.55e7 -- profiles/r06_z_proxy_order.md).
+template <bool CMD>
+__device__ __forceinline__ int qmpc_handover_bin(const QmpcParams& P, const int i, const int first3) {
+  if constexpr (CMD) {
+    return 0;
+  } else {
+    const float* q = P.q + (size_t)i * 4;
+    const float* tr = P.traj + (size_t)i * 12 * P.horizon;
+    const float* wt = P.weights + (size_t)i * P.weights_stride;
+    const float T = (float)P.horizon * (float)P.dt;
+    const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    float x0[3] = {2.f * (qw * qx + qy * qz), 2.f * (qw * qy - qz * qx), P.yaw[i]};
+    float acc = 0.f, wsum = 1e-30f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float er = (x0[k] - tr[k]) + T * (P.w[(size_t)i * 3 + k] - tr[6 + k]);
+      const float ep = (P.p[(size_t)i * 3 + k] - tr[3 + k]) + T * (P.v[(size_t)i * 3 + k] - tr[9 + k]);
+      acc += wt[k] * __builtin_fabsf(er) + wt[3 + k] * __builtin_fabsf(ep);
+      wsum += wt[k] + wt[3 + k];
+    }
+    const float sc = acc / wsum * (float)first3;
+    int bin = (sc > 0.f) ? (int)(6.f * (__log2f(sc) + 8.f)) : 0;  // (NaN: 0)
+    bin = bin < 0 ? 0 : (bin > 63 ? 63 : bin);
+    return 63 - bin;  // hardest first
+  }
+}
 template <int RB, bool CMD>
 __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, const QmpcParams& P) {
   constexpr int NT = Cfg<RB>::NT, NW = NT / 64;
-  static_assert(sizeof(S.u) >= 64 * 4 + 16 * 4 + QMPC_SO_SEG * 5, "size order: scratch in the phase-local storage");
-  int* hist = reinterpret_cast<int*>(&S.u);  // 64 bins
-  int* wcnt = hist + 64;                     // NW wave totals
-  unsigned char* keys = reinterpret_cast<unsigned char*>(wcnt + 16);               // [seg] bin, 0xff = handed on
-  unsigned short* fitpos = reinterpret_cast<unsigned short*>(keys + QMPC_SO_SEG);  // [seg] positions of the fitting robots, index order
-  unsigned short* sorted = fitpos + QMPC_SO_SEG;                                   // [seg] the fitting robots in bin order
+  static_assert(sizeof(S.u) >= 128 * 4 + 32 * 4 + QMPC_SO_SEG * 5, "size order: scratch in the phase-local storage");
+  int* hist = reinterpret_cast<int*>(&S.u);  // 128 bins: 0..63 the robots that fit (by size), 64..127 the robots handed on (by the proxy)
+  int* wcnt = hist + 128;                    // 2 x NW wave totals (fitting, handed on)
+  unsigned char* keys = reinterpret_cast<unsigned char*>(wcnt + 32);            // [seg] bin
+  unsigned short* place = reinterpret_cast<unsigned short*>(keys + QMPC_SO_SEG);  // [seg] the fitting robots' places in index order, then the others'
+  unsigned short* sorted = place + QMPC_SO_SEG;                                  // [seg] the robots in bin order
   const int lane = tid & 63, wv = tid >> 6;
   const int nfs = 4 * P.horizon, maxfit = P.so_maxfit;
   // this workgroup's segment: the robots (and places) s0 + nseg t, t < n -- STRIDED, so that every segment is a sample of the
@@ -3389,81 +3422,118 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
   // so_nseg is a multiple of 8, so a segment's readers sit on its builder's XCD and their one probe is an L2 hit) and written
   // through (sc1) into the far copy, which is what a reader polls if the near probe did not show this call's tag -- whatever
   // the placement, a tag that matches was written in this call, and the far copy is the plain tagged-granule hand-off
-  auto so_put = [&](int place, int robot) __attribute__((always_inline)) {
+  auto so_put = [&](int at, int robot) __attribute__((always_inline)) {
     const unsigned long long v = tag | (unsigned)robot;
-    P.so_order[place] = v;
-    __hip_atomic_store(P.so_far + place, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    P.so_order[at] = v;
+    __hip_atomic_store(P.so_far + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   __builtin_amdgcn_s_setprio(3);
-  if (tid < 64 + NW) hist[tid] = 0;
+  if (tid < 128 + 32) hist[tid] = 0;
   __syncthreads();
   // wave wv: the robots [lo, hi) of the segment, 256 at a time (four per lane: forty loads in flight)
   const int per = ((n + NW - 1) / NW + 63) & ~63;
   const int lo = wv * per, hi = (lo + per < n) ? lo + per : n;
-  int nfit = 0;
+  int nfit = 0, nhand = 0;
   for (int base = lo; base < hi; base += 256) {
     int key[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = base + 64 * u + lane;
-      key[u] = -2;
+      key[u] = -1;
       if (i < hi) {
-        int d;
         if (CMD || P.so_hint) {
-          d = 63 - P.so_hint[gidx(i)];  // (command mode: the contact table exists in registers only -- hint or nothing)
-          d = d < 0 ? 0 : d;
+          const int d = 63 - P.so_hint[gidx(i)];  // (command mode: the contact table exists in registers only -- hint or nothing)
+          key[u] = d < 0 ? 0 : d;
         } else {
-          d = maxfit - qmpc_count_stance(P.gait + (size_t)gidx(i) * nfs, nfs);
+          const uint8_t* g = P.gait + (size_t)gidx(i) * nfs;
+          const int d = maxfit - qmpc_count_stance(g, nfs);
+          if (d >= 0) key[u] = d > 63 ? 63 : d;
+          else key[u] = 64 + qmpc_handover_bin<CMD>(P, gidx(i), qmpc_count_stance(g, nfs < 12 ? nfs : 12));
         }
-        key[u] = (d < 0) ? -1 : (d > 63 ? 63 : d);
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = base + 64 * u + lane;
-      if (key[u] > -2) keys[i] = (unsigned char)key[u];
-      if (key[u] >= 0) atomicAdd(&hist[key[u]], 1);
-      nfit += __popcll(__ballot(key[u] >= 0));
+      if (key[u] >= 0) {
+        keys[i] = (unsigned char)key[u];
+        atomicAdd(&hist[key[u]], 1);
+      }
+      nfit += __popcll(__ballot(key[u] >= 0 && key[u] < 64));
+      nhand += __popcll(__ballot(key[u] >= 64));
     }
   }
-  if (lane == 0) wcnt[wv] = nfit;
+  if (lane == 0) {
+    wcnt[wv] = nfit;
+    wcnt[16 + wv] = nhand;
+  }
   __syncthreads();
-  int wbase = 0, total = 0;
+  if constexpr (!CMD) {
+    // Every fitting robot of the segment has the SAME size (one gait, any phases): the size says nothing, and here the proxy
+    // does order the launch (trot, 8192 robots: +4 %; 4096 at h = 16: +1.6 %, host emulation) -- the fitting robots are keyed
+    // again, by the proxy
+    if (!P.so_hint && __popcll(__ballot(hist[lane] != 0)) == 1) {
+      __syncthreads();  // (every wave has looked at the counts)
+      if (tid < 64) hist[tid] = 0;
+      __syncthreads();
+      for (int base = lo; base < hi; base += 256) {
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = base + 64 * u + lane;
+          key[u] = -1;
+          if (i < hi && keys[i] < 64)
+            key[u] = qmpc_handover_bin<CMD>(P, gidx(i), qmpc_count_stance(P.gait + (size_t)gidx(i) * nfs, nfs < 12 ? nfs : 12));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (key[u] >= 0) {
+            keys[base + 64 * u + lane] = (unsigned char)key[u];
+            atomicAdd(&hist[key[u]], 1);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int fbase = 0, hbase = 0, nfit_all = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
-    const int cw = wcnt[w];
-    wbase += (w < wv) ? cw : 0;
-    total += cw;
+    const int cf = wcnt[w], ch = wcnt[16 + w];
+    fbase += (w < wv) ? cf : 0;
+    hbase += (w < wv) ? ch : 0;
+    nfit_all += cf;
   }
   int excl = 0;
-  if (tid < 64) {  // exclusive prefix over the bins: one wave, six shuffle steps
+  if (tid < 128) {  // exclusive prefix over the bins: six shuffle steps per wave, the second wave starts behind all fitting robots
     const int cnt = hist[tid];
     int acc = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int up = __shfl_up(acc, d);
-      if (tid >= d) acc += up;
+      if (lane >= d) acc += up;
     }
-    excl = acc - cnt;
+    excl = acc - cnt + (tid >= 64 ? nfit_all : 0);
   }
   __syncthreads();  // (everybody has read the wave totals and the counts)
-  if (tid < 64) hist[tid] = excl;
+  if (tid < 128) hist[tid] = excl;
   __syncthreads();
-  int run = wbase;
+  int runf = fbase, runh = nfit_all + hbase;
   for (int base = lo; base < hi; base += 64) {
     const int i = base + lane;
-    const int key = (i < hi) ? (int)keys[i] : 0xfe;
-    const bool fit = key < 64;
-    const unsigned long long m = __ballot(fit);
-    if (key == 0xff) so_put(gidx(i), gidx(i));  // handed on: keeps its place
-    if (fit) {
-      fitpos[run + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
-      sorted[atomicAdd(&hist[key], 1)] = (unsigned short)i;
-    }
-    run += __popcll(m);
+    const int key = (i < hi) ? (int)keys[i] : 0xff;
+    const bool fit = key < 64, hand = key >= 64 && key < 128;
+    const unsigned long long mf = __ballot(fit), mh = __ballot(hand);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (fit) place[runf + __popcll(mf & below)] = (unsigned short)i;
+    if (hand) place[runh + __popcll(mh & below)] = (unsigned short)i;
+    if (fit || hand) sorted[atomicAdd(&hist[key], 1)] = (unsigned short)i;
+    runf += __popcll(mf);
+    runh += __popcll(mh);
   }
   __syncthreads();
-  for (int k = tid; k < total; k += NT) so_put(gidx(fitpos[k]), gidx(sorted[k]));
+  // k < nfit_all: the k-th place of a fitting robot takes the k-th fitting robot in bin order; beyond: the same among the others
+  for (int k = tid; k < n; k += NT) so_put(gidx(place[k]), gidx(sorted[k]));
   __syncthreads();  // (the scratch is the solve's from here on)
   __builtin_amdgcn_s_setprio(0);
 }

@@ -25,23 +25,28 @@ def feats(b):
     return werr, g.sum((1, 2)), g[:, :3].sum((1, 2))
 
 
-out = []
-for name, b, steps, maxfit in (("cfg4", W.make_config(4, batch=8192), 20, 21), ("cfg2", W.make_config(2), 40, 21), ("cfg2_8192", W.make_config(2, batch=8192), 20, 21),
-                               ("cfg3", W.make_config(3, batch=4096), 10, 32)):
-    B = int(b["batch"])
-    werr, nst, first3 = feats(b)
-    fit = nst <= maxfit
-    scores = {"nst": nst.astype(float), "werr_x_nst": werr * nst, "werr_x_first3": werr * first3, "werr": werr,
-              "nst_plus": nst * (1.0 + werr / werr.mean())}
-    r = {"workload": name, "plain": B / run(b, 0, steps)[0] * 1e3}
-    for k, sc in scores.items():
-        fo = np.argsort(np.where(fit, -sc, np.inf), kind="stable")[:fit.sum()]
-        perm = interleave(fo, np.nonzero(~fit)[0]) if (~fit).any() else fo
-        r[k] = B / run(permute(b, perm), 0, steps)[0] * 1e3
-        if (~fit).any():
-            po = np.argsort(np.where(~fit, -sc, np.inf), kind="stable")[:(~fit).sum()]
-            r[k + "+passes_too"] = B / run(permute(b, interleave(fo, po)), 0, steps)[0] * 1e3
-            r[k + "_all"] = B / run(permute(b, np.argsort(-sc, kind="stable")), 0, steps)[0] * 1e3
-    out.append(r)
-    print(name, {k: (round(v / 1e7, 3) if k != "workload" else v) for k, v in r.items()}, file=sys.stderr)
-print(json.dumps(out, indent=1))
+def main():
+    out = []
+    for name, b, steps, maxfit in (("cfg4", W.make_config(4, batch=8192), 20, 21), ("cfg2", W.make_config(2), 40, 21), ("cfg2_8192", W.make_config(2, batch=8192), 20, 21),
+                                   ("cfg3", W.make_config(3, batch=4096), 10, 32)):
+        B = int(b["batch"])
+        werr, nst, first3 = feats(b)
+        fit = nst <= maxfit
+        scores = {"nst": nst.astype(float), "werr_x_nst": werr * nst, "werr_x_first3": werr * first3, "werr": werr,
+                  "nst_plus": nst * (1.0 + werr / werr.mean())}
+        r = {"workload": name, "plain": B / run(b, 0, steps)[0] * 1e3}
+        for k, sc in scores.items():
+            fo = np.argsort(np.where(fit, -sc, np.inf), kind="stable")[:fit.sum()]
+            perm = interleave(fo, np.nonzero(~fit)[0]) if (~fit).any() else fo
+            r[k] = B / run(permute(b, perm), 0, steps)[0] * 1e3
+            if (~fit).any():
+                po = np.argsort(np.where(~fit, -sc, np.inf), kind="stable")[:(~fit).sum()]
+                r[k + "+passes_too"] = B / run(permute(b, interleave(fo, po)), 0, steps)[0] * 1e3
+                r[k + "_all"] = B / run(permute(b, np.argsort(-sc, kind="stable")), 0, steps)[0] * 1e3
+        out.append(r)
+        print(name, {k: (round(v / 1e7, 3) if k != "workload" else v) for k, v in r.items()}, file=sys.stderr)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,9 @@ if __name__ == "__main__":
                                       ("cfg2_8192", W.make_config(2, batch=8192), 20, True), ("cfg2_2048", W.make_config(2, batch=2048), 40, True),
                                       ("cfg2_16384", W.make_config(2, batch=16384), 10, True), ("cfg4_16384", W.make_config(4, batch=16384), 10, True),
                                       ("cfg4_nohints", W.make_config(4, batch=8192), 20, False), ("cfg3_nohints", W.make_config(3, batch=4096), 10, False),
-                                      ("cfg1_8192_nohints", W.make_config(1, batch=8192), 20, False)):
+                                      ("cfg1_8192_nohints", W.make_config(1, batch=8192), 20, False),
+                                      ("cfg3", W.make_config(3, batch=4096), 10, True), ("cfg1_8192", W.make_config(1, batch=8192), 20, True),
+                                      ("cfg1_4096", W.make_config(1, batch=4096), 30, True), ("cfg1_16384", W.make_config(1, batch=16384), 10, True)):
             r = ab(name, b, steps, hints)
             r["so_first_pct"] = pct
             out.append(r)
