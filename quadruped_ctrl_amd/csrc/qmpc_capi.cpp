@@ -173,7 +173,10 @@ struct qmpc_ctx {
   int size_order = 1;
   unsigned long long* d_so_order = nullptr;  // [max_batch] (call number << 32 | robot)
   unsigned so_call = 0;
+  unsigned long long* d_prio_cu = nullptr;  // [2048] one-round launches without a hint: one word per CU (qmpc_device.h: prio_cu)
+  unsigned prio_call = 0;
   int so_first_pct = 50;
+  int so_tail_rounds = 5;
   int hint_prepass = 0;  // 1: the order hint's permutation by a sort kernel in front of the call (as until round 6)
   int hint_batch = 0;           // batch size of the call that wrote d_hint_iters (0: none yet)
   int hint_hard = 5;            // single-round launches: iterations in the previous call from which a robot may keep the highest issue priority (0 = off)
@@ -299,6 +302,8 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   if (e == hipSuccess) e = hipMalloc(&c->d_hint_iters, sizeof(int) * (2 * (size_t)max_batch + 4 + 2048));
   if (e == hipSuccess) e = hipMemset(c->d_hint_iters, 0, sizeof(int) * (2 * (size_t)max_batch + 4 + 2048));
   if (e == hipSuccess) c->d_order = c->d_hint_iters + max_batch;
+  if (e == hipSuccess) e = hipMalloc(&c->d_prio_cu, sizeof(unsigned long long) * 2048);
+  if (e == hipSuccess) e = hipMemset(c->d_prio_cu, 0, sizeof(unsigned long long) * 2048);
   if (e == hipSuccess) e = hipMalloc(&c->d_so_order, sizeof(unsigned long long) * 2 * (size_t)max_batch);  // near copy, far copy
   if (e == hipSuccess) e = hipMemset(c->d_so_order, 0, sizeof(unsigned long long) * 2 * (size_t)max_batch);  // (call numbers start at 1)
   if (e == hipSuccess) c->d_hint_max = c->d_hint_iters + 2 * (size_t)max_batch;
@@ -306,6 +311,8 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = (ns && ns[0] == '1') ? 0 : 1;
+    const char* st = std::getenv("QMPC_SO_TAIL_ROUNDS");
+    if (st && std::atoi(st) > 0) c->so_tail_rounds = std::atoi(st);
     const char* sf = std::getenv("QMPC_SO_FIRST_PCT");  // (measurement knob: the unsorted head of a size-ordered launch, % of a round beyond the first)
     if (sf) c->so_first_pct = std::atoi(sf);
     const char* hp = std::getenv("QMPC_HINT_PREPASS");
@@ -362,6 +369,7 @@ int qmpc_destroy(qmpc_handle h) {
     if (h->d_fb_lists) hipFree(h->d_fb_lists);
     if (h->d_hint_iters) hipFree(h->d_hint_iters);
     if (h->d_so_order) hipFree(h->d_so_order);
+    if (h->d_prio_cu) hipFree(h->d_prio_cu);
     for (int k = 0; k < 3; ++k) {
       if (h->d_wk_hinv[k]) hipFree(h->d_wk_hinv[k]);
       if (h->d_wk_xu[k]) hipFree(h->d_wk_xu[k]);
@@ -1049,8 +1057,14 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         const int head = (int)((long long)res * c->so_first_pct / 100);
         const int half = (batch - res) / 2 < head ? (batch - res) / 2 : head;
         P.so_first = (res + half + 7) & ~7;
+        // (a launch of many rounds: only its last five are ordered -- a robot lasts three or four rounds at most, so nothing that
+        //  starts earlier can end the launch, and every reader pays a memory round trip for its entry: trot, 16384 robots, -3.9 %
+        //  with everything ordered)
+        if (batch - c->so_tail_rounds * res > P.so_first) P.so_first = (batch - c->so_tail_rounds * res + 7) & ~7;
         const int n = batch - P.so_first;
-        if (n >= 64 && 17 * 8 * ((n + 8 * 4080 - 1) / (8 * 4080)) <= P.so_first) {
+        // (fewer than half a round to order: the builders and the sixteen first-round places per segment cost more than the
+        //  order gives -- mixed gaits, 2048 robots on 1280 slots: -5.5 %)
+        if (2 * n >= res && 17 * 8 * ((n + 8 * 4080 - 1) / (8 * 4080)) <= res) {
           // strided segments of at most 4096 robots (QMPC_SO_SEG of qmpc_kernels.hip: the builder's LDS scratch)
           // (a multiple of 8, and so_first too: place b of segment j has b % 8 == j % 8 -- readers and builder on one XCD)
           // (QMPC_SO_HEAD = 16 places of the first round per segment on top: 17 nseg workgroups in front of so_first)
@@ -1064,7 +1078,23 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         }
       }
     }
+    // ONE round, workgroups sharing CUs, no usable hint: the sweep's issue priority is staged by the tracking-error proxy's rank
+    // within the launch (qmpc_kernels.hip, stage 0) -- same conditions as the size order (record mode: the proxy reads the record)
+    P.prio_cu = nullptr;
+    if (!listed && !capturing && !P.admm_mode && c->size_order && !cmd && P.gait && ((uintptr_t)P.gait & 3u) == 0 && P.hint_hard <= 0) {
+      const int res = qmpc_resident_blocks(kcls);
+      // (only where the CUs are full: at three workgroups per CU -- 768 robots on 1024 slots -- the staging costs 3 %)
+      if (res > 0 && batch <= res && 8 * batch > 7 * res) {
+        P.prio_cu = c->d_prio_cu;
+        P.prio_tag = ++c->prio_call;
+        if (P.prio_tag == 0) {  // (the call number wrapped: the words start again)
+          HIP_TRY(c, fill_ints(reinterpret_cast<int*>(c->d_prio_cu), 2 * 2048, 0, stream));
+          P.prio_tag = ++c->prio_call;
+        }
+      }
+    }
     HIP_TRY(c, qmpc_launch(kcls, &P, grid, stream));
+    P.prio_cu = nullptr;
     P.so_order = nullptr;
     P.order = nullptr;
     P.hint_hard = 0;

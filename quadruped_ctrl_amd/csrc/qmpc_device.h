@@ -208,6 +208,11 @@ struct QmpcParams {
   const int32_t* hint_max_r;
   int32_t* hint_max_w;
   int32_t* hint_max_z;
+  // one-round launches without a usable hint: one word per CU ([xcc 3 bits][se, sh, cu 8 bits]) on which the workgroups that share
+  // it post (prio_tag << 32 | hardness by the tracking-error proxy << 24 | robot) with an atomic maximum; the one whose entry
+  // stands keeps issue priority 3 through its sweep.  prio_tag: a per-handle call number (nullptr = off)
+  unsigned long long* prio_cu;
+  unsigned prio_tag;
   // size order (qmpc_kernels.hip: size_order_build; nullptr = off): in a launch of several rounds the workgroups from so_first on
   // take robot so_order[blockIdx.x] -- the robots that fit the class largest first (by their contact tables) within so_nseg
   // strided segments (robot so_first + j + so_nseg t: segment j), segment j built by workgroup j of the same launch; entries are

@@ -176,6 +176,93 @@ __device__ __forceinline__ void fmac8_rowbcast(double (&a)[8], double c, double 
       : "v"(c), "v"(u));
 }
 
+// ---- what a robot will cost, guessed from its record before anything is solved ----
+// nst: stance foot-steps (the reduced size is 3 nst: the sweep is that many half-steps long).
+// score: a proxy of the active-set iteration count,
+//     score = first3 * sum_k Q_k |e_k + T de_k| / sum_k Q_k  +  0.15 * max(0, L1 * sa - 1.5)
+//   first term: the tracking error the COASTING state would have at the end of the horizon (orientation and position rows,
+//   T = h dt; small-angle roll / pitch: a proxy), relative to the weights, times the stance foot-steps of the first three
+//   segments -- the forces that would have to correct it are the ones that run into their bounds;
+//   second term: the FIRST support phase (leading flight skipped): L1 segments on one stance set whose centroid is off the
+//   centre of mass by c; gravity's moment about it can only be balanced by tangential force, sat = |c| / (height mu) of the
+//   friction limit (pacing 0.95, bounding 1.65, trot 0); sa = min(sat, 1) where sat > 0.6.  A long asymmetric first phase is
+//   what makes a pacing / bounding robot iterate ten times where a trotting one needs two (configs[2], 30 contact tables).
+//   Correlation with the iteration count: configs[1] 0.76, [2] 0.75, [3] 0.69, [4] 0.74 (the size alone: 0.03 ... 0.24).
+//   One formula, constants fitted once on those four workloads (profiles/r06_z_proxy_order.md); it ORDERS work, nothing else.
+__device__ __forceinline__ unsigned qmpc_stance_set(const uint32_t w) {  // the four contact bytes of a segment -> 4-bit set
+  const uint32_t t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // bit 7 of every nonzero byte
+  return ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+}
+struct QmpcKeys {
+  int nst;
+  float score;
+};
+__device__ __forceinline__ QmpcKeys qmpc_robot_keys(const QmpcParams& P, const int i) {
+  const int h = P.horizon;
+  // (4 h bytes per robot, the base 4-byte aligned: the host checks)
+  const uint32_t* g4 = reinterpret_cast<const uint32_t*>(P.gait + (size_t)i * 4 * h);
+  int nst = 0, first3 = 0, run = 0;
+  unsigned set0 = 0u;
+  bool open = true;
+  for (int k = 0; k < h; ++k) {
+    const unsigned m = qmpc_stance_set(g4[k]);
+    const int c = __builtin_popcount(m);
+    nst += c;
+    first3 += (k < 3) ? c : 0;
+    if (open) {
+      if (set0 == 0u) {
+        set0 = m;
+        run = m ? 1 : 0;
+      } else if (m == set0) {
+        ++run;
+      } else {
+        open = false;
+      }
+    }
+  }
+  const float* q = P.q + (size_t)i * 4;
+  const float* tr = P.traj + (size_t)i * 12 * h;
+  const float* wt = P.weights + (size_t)i * P.weights_stride;
+  const float T = (float)h * (float)P.dt;
+  const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  const float x0[3] = {2.f * (qw * qx + qy * qz), 2.f * (qw * qy - qz * qx), P.yaw[i]};
+  float acc = 0.f, wsum = 1e-30f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float er = (x0[k] - tr[k]) + T * (P.w[(size_t)i * 3 + k] - tr[6 + k]);
+    const float ep = (P.p[(size_t)i * 3 + k] - tr[3 + k]) + T * (P.v[(size_t)i * 3 + k] - tr[9 + k]);
+    acc += wt[k] * __builtin_fabsf(er) + wt[3 + k] * __builtin_fabsf(ep);
+    wsum += wt[k] + wt[3 + k];
+  }
+  float score = acc / wsum * (float)first3;
+  if (set0 != 0u) {
+    const float* r = P.r + (size_t)i * 12;  // r[axis * 4 + foot]
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const float on = ((set0 >> f) & 1u) ? 1.f : 0.f;
+      cx += on * r[f];
+      cy += on * r[4 + f];
+      cz += on * r[8 + f];
+    }
+    const float inv = 1.f / (float)__builtin_popcount(set0);
+    cx *= inv;
+    cy *= inv;
+    cz = __builtin_fabsf(cz * inv);
+    const float sat = __builtin_sqrtf(cx * cx + cy * cy) * (float)P.mu_inv / (cz > 1e-3f ? cz : 1e-3f);
+    const float sa = sat > 0.6f ? (sat < 1.f ? sat : 1.f) : 0.f;
+    const float pat = (float)run * sa - 1.5f;
+    score += 0.15f * (pat > 0.f ? pat : 0.f);
+  }
+  return {nst, score};
+}
+// score -> `per` logarithmic levels per octave from 2^-6 on, `levels` of them, HARDEST = 0 (a NaN: the easiest)
+__device__ __forceinline__ int qmpc_score_level(const float score, const float per, const int levels) {
+  int b = (score > 0.f) ? (int)(per * (__log2f(score) + 6.f)) : 0;
+  b = b < 0 ? 0 : (b > levels - 1 ? levels - 1 : b);
+  return levels - 1 - b;
+}
+
 // Size classes.  RB names the class: 1, 2, 3 = 64 / 128 / 192 padded rows (four column
 // groups of 16 RB columns, 256 RB threads); 4 = the 96-row class between 1 and 2 (four
 // groups of 24 columns, 384 threads, two workgroups per CU) that catches n_r <= 96 --
@@ -266,6 +353,7 @@ struct Smem {
   int mode;  // set by the engine wave: != 0 -> the robot must be re-run with the fallback engine
   int evslot;  // class 3: this workgroup's slice of the global event pool
   int qnext;   // next entry of the work list (classes launched after the first)
+  int prio_rank;  // one-round launches without a hint: 0 = the hardest robot of its CU by the tracking-error proxy
   int bal_simd[8], bal_cu, bal_bit;  // balance_waves: where the launched waves landed, this CU's slot word, the bit taken
   // the engine wave's request to the helper waves (event-form engine, classes with NHELP > 0)
   struct Help {
@@ -380,7 +468,7 @@ __device__ __forceinline__ void qmpc_census_dump(Smem<RB>& S, const QmpcParams& 
 // minimiser as below, then the inverse goes to the robot's work item in global memory (L2 / Infinity-Cache
 // resident) instead of LDS and the workgroup moves on; the active set is run by qmpc_engine_kernel
 // (qmpc_engine.hip) -- a workgroup of the large classes no longer pins a whole CU while one of its waves iterates.
-template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false, bool PHA = false, bool BIG = false>
+template <int RB, bool V5, bool CMD, bool ADMM = false, bool WARM = false, bool PHA = false, bool BIG = false, bool PRIO = false>
 __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>& S, const QmpcParams& PK) {
   using C = Cfg<RB>;
   constexpr int NP = C::NP, CW = C::CW, NT = C::NT, KMAX = C::KMAX, KW = C::KW, RE = C::RE;
@@ -422,6 +510,25 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     hfloor = hard ? 3 : ((mine >= PK.hint_hard && 5 * mine >= 2 * top && ge <= 4) ? 2 : 0);
   }
 
+  // ONE-ROUND launch without a usable hint (prio_cu != nullptr): the workgroups that share a CU compete for its issue
+  // slots, and the CU is done when the LAST of them is -- the one that iterates longest.  Which one that will be is guessed from
+  // the tracking-error proxy (qmpc_robot_keys: correlation with the iteration count 0.69 ... 0.76 -- configs[1]'s
+  // 13-iteration robot is third of 1024): a thread that has nothing else to do in stage 0 evaluates it right away, beside
+  // everybody's loads, and posts (call number, hardness, robot) with ONE atomic maximum on its CU's word (four arrivals per word,
+  // served by the XCD's L2; a newer call's number beats whatever an older call left: nothing to reset) ...
+  unsigned long long prio_mine = 0ull;
+  unsigned long long* prio_word = nullptr;
+  if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
+    if (PK.prio_cu && tid == NT - 1) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      prio_word = PK.prio_cu + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu));
+      const int pb = qmpc_score_level(qmpc_robot_keys(PK, rid).score, 6.f, 64);
+      prio_mine = ((unsigned long long)PK.prio_tag << 32) | ((unsigned long long)(63 - pb) << 24) | (unsigned)(rid & 0xffffff);
+      __hip_atomic_fetch_max(prio_word, prio_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // ------------------------------------------------------------ stage 0
   // Every global load of the robot's record is issued up front (one memory
   // latency for the whole stage); then: contact table -> compact stance list
@@ -703,6 +810,12 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   if (dbg_clk && tid == 0) dbg_clk[12] = clock64();
   __syncthreads();  // ---- barrier 1
   QMPC_TICK(1);
+  // ... and a stage later reads the word back: the robot whose entry stands is the CU's hardest and keeps the top priority through
+  // its sweep (S.prio_rank = 0), the others yield as they advance, as ever.  The barriers of stage 1 publish it
+  if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
+    if (PK.prio_cu && tid == NT - 1)
+      S.prio_rank = (__hip_atomic_load(prio_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prio_mine) ? 0 : 1;
+  }
   {
     const double keep0[2] = {(double)g_alpha, x_drag};
     (void)keep0;
@@ -1453,6 +1566,16 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   // (P^-1 C^T); since a_kj == c_j they get it from the same update with
   // F_k = I - P^-1, so the update has no row special-casing.
   bool notpd = false;
+  bool staged = PK.hint_hard > 0;  // one-round staging of the sweep's issue priority: by the hint, or by the proxy's rank
+  if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
+    if (PK.prio_cu) {  // (S.prio_rank: written before stage 1's barriers)
+      const int rank = __builtin_amdgcn_readfirstlane(S.prio_rank);
+      if (QMPC_DBG_ITER == 0 && dbg_clk && tid == 0) dbg_clk[14] = rank;  // (profiling hook)
+      hard = rank == 0;
+      hfloor = hard ? 3 : 0;
+      staged = true;
+    }
+  }
   if constexpr (C::C1) {
     // Class 1: a column group is exactly one wave (lane == row), so the wave that
     // owns the NEXT pivot pair reads its 2x2 pivot block with readlane, inverts it
@@ -1534,7 +1657,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       // dispatched used to sweep at full speed (24k cycles) and the last one at half
       // (50k) -- and a launch ends with its slowest workgroup.  A wave that is ahead now
       // yields to the ones behind it.
-      if (hard || (kb == 0 && PK.hint_hard <= 0)) __builtin_amdgcn_s_setprio(3);
+      if (hard || (kb == 0 && !staged)) __builtin_amdgcn_s_setprio(3);
       else if (kb <= 1 || hfloor >= 2) __builtin_amdgcn_s_setprio(2);
       else if (kb == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
@@ -1588,7 +1711,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
             QMPC_PIN;
             fmac4_rowbcast<G3>(a, cv1, nu1);
 #if QMPC_PROD_PRIO
-            if (hard || (kb == 0 && PK.hint_hard <= 0)) __builtin_amdgcn_s_setprio(3);
+            if (hard || (kb == 0 && !staged)) __builtin_amdgcn_s_setprio(3);
             else if (kb <= 1 || hfloor >= 2) __builtin_amdgcn_s_setprio(2);
             else if (kb == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
@@ -1653,7 +1776,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     for (int kb = 0; kb < 4; ++kb) {
 #if QMPC_SWEEP_PRIO
       // see the class-1 loop: a wave that is ahead yields issue slots to the ones behind it
-      if (hard || (kb == 0 && PK.hint_hard <= 0)) __builtin_amdgcn_s_setprio(3);
+      if (hard || (kb == 0 && !staged)) __builtin_amdgcn_s_setprio(3);
       else if (kb <= 1 || hfloor >= 2) __builtin_amdgcn_s_setprio(2);
       else if (kb == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
@@ -3216,12 +3339,12 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
 // one robot with the engine pair of its class: event-form engine first (it continues in global memory when its
 // on-chip pool fills up); the (rare) robot that runs out of working-set SLOTS there is solved again from scratch
 // with the Schur-form engine, which has more of them
-template <int RB, bool CMD, bool WARM>
+template <int RB, bool CMD, bool WARM, bool PRIO = false>
 __device__ __forceinline__ void solve_robot(const int rid, const int tid, Smem<RB>& S, const QmpcParams& P) {
   if constexpr (Cfg<RB>::EVENT_ENGINE) {
     bool again;
     if (Cfg<RB>::GLOBAL_EVENTS && S.evslot < 0) again = true;  // no pool slice (pool_acquire timed out): Schur form only
-    else again = solve_one<RB, true, CMD, false, WARM>(rid, tid, S, P);
+    else again = solve_one<RB, true, CMD, false, WARM, false, false, PRIO>(rid, tid, S, P);
     if (again) {
       __syncthreads();
       // opaque thread id: without it the compiler keeps per-thread values of the
@@ -3330,12 +3453,13 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
 }
 
 // SIZE ORDER: a launch of several rounds of workgroups ends with whichever long robot started last.  What a
-// robot will cost is not known before its inverse exists -- except for its reduced size n_r = 3 x stance foot-steps, which
-// is in its contact table: the sweep is n_r / 2 steps long, and the smaller problems' iteration counts have the shorter
-// tail (configs[2]: bounding, 48 rows, at most 17 iterations; trot / pacing, 60 rows, up to 23).  So the workgroups
-// beyond so_first (about 1.5 rounds) take the robots THAT FIT THIS CLASS largest first; the robots the class only hands on
-// stay among their own places (bunching those costs more than any order of theirs gives: they hide behind their neighbours'
-// sweeps) and are ordered among themselves for the NEXT class's sake (qmpc_handover_bin below).
+// robot will cost is not known before its inverse exists -- but its record says a good deal (qmpc_robot_keys above): the
+// reduced size n_r = 3 x stance foot-steps (the sweep is n_r / 2 steps long) and a score that follows the iteration count
+// with a correlation of 0.7.  So the workgroups beyond so_first (about 1.5 rounds) take the robots THAT FIT THIS CLASS largest
+// first and, among equals, highest score first; the robots the class only hands on stay among their own places (bunching those
+// costs more than any order of theirs gives: they hide behind their neighbours' sweeps) and are ordered among themselves by
+// the score, for the NEXT class's sake: its queue is filled in dispatch order, and that launch (two workgroups per CU, robots
+// that iterate up to forty times) ends with whichever long robot it took last.
 // The permutation is built INSIDE the launch while the first rounds are being solved -- a sort kernel in front of the launch
 // would cost what the order gives (4 us of 126): the robots from so_first on are dealt to so_nseg segments of at most 4096
 // (robot so_first + j + nseg t belongs to segment j), workgroup j sorts segment j WITHIN itself before it solves its own robot
@@ -3348,63 +3472,26 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
 // its own record).
 #define QMPC_SO_SEG 4096
 #define QMPC_SO_HEAD 16  // robots / places of the first round per segment (qmpc_capi.cpp sizes the segments: QMPC_SO_SEG - QMPC_SO_HEAD strided robots at most)
-__device__ __forceinline__ int qmpc_count_stance(const uint8_t* __restrict__ g, const int nfs) {
-  // nonzero bytes of the 4 h-byte contact table (4 h is a multiple of 4, the base is 8-byte aligned: the host checks)
-  const uint32_t* g4 = reinterpret_cast<const uint32_t*>(g);
-  int nst = 0;
-  for (int k = 0; k < (nfs >> 2); ++k) {
-    const uint32_t w = g4[k];
-    const uint32_t t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // bit 7 of every nonzero byte
-    nst += __builtin_popcount(t);
-  }
-  return nst;
-}
 // The same builder serves the ORDER HINT (so_hint != nullptr: the iteration counts the handle's previous call left, one per
 // robot): key = the count, every robot takes part (a robot that is handed on carries the count of the class that solved it,
 // so the next class's queue comes out hardest first as well) -- in place of a sort kernel in front of the call.
-// A robot this class only HANDS ON is ordered as well -- among the places of the robots handed on, so that nothing bunches: the
-// next class's queue is filled in dispatch order, and that launch (two workgroups per CU, robots that iterate up to forty times)
-// ends with whichever long robot it took last.  Key: the tracking error the COASTING state would have at the end of the horizon,
-// sum_k Q_k |e_k + T de_k| / sum_k Q_k over orientation and position (T = h dt; small-angle roll / pitch: a proxy), times the stance
-// foot-steps of the first three segments -- correlation with the iteration count 0.74 on configs[4]'s robots (0.24 for the size
-// alone), hardest first in 64 logarithmic bins (six per octave).  NOT for the robots that fit: on configs[2] any order by
-// this key is worse than none (3.15e7 against 3.22e7; by size 3.55e7 -- profiles/r06_z_proxy_order.md).
-template <bool CMD>
-__device__ __forceinline__ int qmpc_handover_bin(const QmpcParams& P, const int i, const int first3) {
-  if constexpr (CMD) {
-    return 0;
-  } else {
-    const float* q = P.q + (size_t)i * 4;
-    const float* tr = P.traj + (size_t)i * 12 * P.horizon;
-    const float* wt = P.weights + (size_t)i * P.weights_stride;
-    const float T = (float)P.horizon * (float)P.dt;
-    const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-    float x0[3] = {2.f * (qw * qx + qy * qz), 2.f * (qw * qy - qz * qx), P.yaw[i]};
-    float acc = 0.f, wsum = 1e-30f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float er = (x0[k] - tr[k]) + T * (P.w[(size_t)i * 3 + k] - tr[6 + k]);
-      const float ep = (P.p[(size_t)i * 3 + k] - tr[3 + k]) + T * (P.v[(size_t)i * 3 + k] - tr[9 + k]);
-      acc += wt[k] * __builtin_fabsf(er) + wt[3 + k] * __builtin_fabsf(ep);
-      wsum += wt[k] + wt[3 + k];
-    }
-    const float sc = acc / wsum * (float)first3;
-    int bin = (sc > 0.f) ? (int)(6.f * (__log2f(sc) + 8.f)) : 0;  // (NaN: 0)
-    bin = bin < 0 ? 0 : (bin > 63 ? 63 : bin);
-    return 63 - bin;  // hardest first
-  }
-}
+// keys of the builder: a robot that FITS this class 16 * size level + score level (size first: 32 levels, largest = 0; then 16
+// score levels, two per octave, hardest = 0) -- host emulation of the orders on configs[2]: by size 3.54e7, by score 3.70e7, size
+// then score 3.96e7 QP/s (plain 3.22e7; profiles/r06_z_proxy_order.md) --; a robot that is only handed on 512 + one of 64 score
+// levels (six per octave); with the order hint 8 * (63 - the previous call's count).
+#define QMPC_SO_BINS 576
 template <int RB, bool CMD>
 __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, const QmpcParams& P) {
   constexpr int NT = Cfg<RB>::NT, NW = NT / 64;
-  static_assert(sizeof(S.u) >= 128 * 4 + 32 * 4 + QMPC_SO_SEG * 5, "size order: scratch in the phase-local storage");
-  int* hist = reinterpret_cast<int*>(&S.u);  // 128 bins: 0..63 the robots that fit (by size), 64..127 the robots handed on (by the proxy)
-  int* wcnt = hist + 128;                    // 2 x NW wave totals (fitting, handed on)
-  unsigned char* keys = reinterpret_cast<unsigned char*>(wcnt + 32);            // [seg] bin
-  unsigned short* place = reinterpret_cast<unsigned short*>(keys + QMPC_SO_SEG);  // [seg] the fitting robots' places in index order, then the others'
-  unsigned short* sorted = place + QMPC_SO_SEG;                                  // [seg] the robots in bin order
+  constexpr int BPT = (QMPC_SO_BINS + NT - 1) / NT;  // bins per thread of the prefix
+  static_assert(sizeof(S.u) >= QMPC_SO_BINS * 4 + 48 * 4 + QMPC_SO_SEG * 6, "size order: scratch in the phase-local storage");
+  int* hist = reinterpret_cast<int*>(&S.u);  // QMPC_SO_BINS counts, then offsets
+  int* wcnt = hist + QMPC_SO_BINS;           // [0..15] fitting robots per wave, [16..31] handed on, [32..47] the prefix's wave totals
+  unsigned short* keys = reinterpret_cast<unsigned short*>(wcnt + 48);  // [seg] bin (0xffff: nobody)
+  unsigned short* place = keys + QMPC_SO_SEG;    // [seg] the fitting robots' places in index order, then the others'
+  unsigned short* sorted = place + QMPC_SO_SEG;  // [seg] the robots in bin order
   const int lane = tid & 63, wv = tid >> 6;
-  const int nfs = 4 * P.horizon, maxfit = P.so_maxfit;
+  const int maxfit = P.so_maxfit;
   // this workgroup's segment: the robots (and places) s0 + nseg t, t < n -- STRIDED, so that every segment is a sample of the
   // whole batch and the t-th largest robots of all segments land next to each other: the launch as a whole runs from large to
   // small without the builders exchanging a word
@@ -3428,39 +3515,39 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
     __hip_atomic_store(P.so_far + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   __builtin_amdgcn_s_setprio(3);
-  if (tid < 128 + 32) hist[tid] = 0;
+  for (int k = tid; k < QMPC_SO_BINS + 48; k += NT) hist[k] = 0;
   __syncthreads();
-  // wave wv: the robots [lo, hi) of the segment, 256 at a time (four per lane: forty loads in flight)
+  // wave wv: the robots [lo, hi) of the segment, 128 at a time (two per lane: their loads in flight together)
   const int per = ((n + NW - 1) / NW + 63) & ~63;
   const int lo = wv * per, hi = (lo + per < n) ? lo + per : n;
   int nfit = 0, nhand = 0;
-  for (int base = lo; base < hi; base += 256) {
-    int key[4];
+  for (int base = lo; base < hi; base += 128) {
+    int key[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int i = base + 64 * u + lane;
       key[u] = -1;
       if (i < hi) {
         if (CMD || P.so_hint) {
           const int d = 63 - P.so_hint[gidx(i)];  // (command mode: the contact table exists in registers only -- hint or nothing)
-          key[u] = d < 0 ? 0 : d;
+          key[u] = 8 * (d < 0 ? 0 : d);
         } else {
-          const uint8_t* g = P.gait + (size_t)gidx(i) * nfs;
-          const int d = maxfit - qmpc_count_stance(g, nfs);
-          if (d >= 0) key[u] = d > 63 ? 63 : d;
-          else key[u] = 64 + qmpc_handover_bin<CMD>(P, gidx(i), qmpc_count_stance(g, nfs < 12 ? nfs : 12));
+          const QmpcKeys kk = qmpc_robot_keys(P, gidx(i));
+          const int d = maxfit - kk.nst;
+          if (d >= 0) key[u] = 16 * (d > 31 ? 31 : d) + qmpc_score_level(kk.score, 2.f, 16);
+          else key[u] = 512 + qmpc_score_level(kk.score, 6.f, 64);
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int i = base + 64 * u + lane;
       if (key[u] >= 0) {
-        keys[i] = (unsigned char)key[u];
+        keys[i] = (unsigned short)key[u];
         atomicAdd(&hist[key[u]], 1);
       }
-      nfit += __popcll(__ballot(key[u] >= 0 && key[u] < 64));
-      nhand += __popcll(__ballot(key[u] >= 64));
+      nfit += __popcll(__ballot(key[u] >= 0 && key[u] < 512));
+      nhand += __popcll(__ballot(key[u] >= 512));
     }
   }
   if (lane == 0) {
@@ -3468,34 +3555,6 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
     wcnt[16 + wv] = nhand;
   }
   __syncthreads();
-  if constexpr (!CMD) {
-    // Every fitting robot of the segment has the SAME size (one gait, any phases): the size says nothing, and here the proxy
-    // does order the launch (trot, 8192 robots: +4 %; 4096 at h = 16: +1.6 %, host emulation) -- the fitting robots are keyed
-    // again, by the proxy
-    if (!P.so_hint && __popcll(__ballot(hist[lane] != 0)) == 1) {
-      __syncthreads();  // (every wave has looked at the counts)
-      if (tid < 64) hist[tid] = 0;
-      __syncthreads();
-      for (int base = lo; base < hi; base += 256) {
-        int key[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = base + 64 * u + lane;
-          key[u] = -1;
-          if (i < hi && keys[i] < 64)
-            key[u] = qmpc_handover_bin<CMD>(P, gidx(i), qmpc_count_stance(P.gait + (size_t)gidx(i) * nfs, nfs < 12 ? nfs : 12));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (key[u] >= 0) {
-            keys[base + 64 * u + lane] = (unsigned char)key[u];
-            atomicAdd(&hist[key[u]], 1);
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
   int fbase = 0, hbase = 0, nfit_all = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
@@ -3504,25 +3563,37 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
     hbase += (w < wv) ? ch : 0;
     nfit_all += cf;
   }
-  int excl = 0;
-  if (tid < 128) {  // exclusive prefix over the bins: six shuffle steps per wave, the second wave starts behind all fitting robots
-    const int cnt = hist[tid];
-    int acc = cnt;
+  // exclusive prefix over the bins: BPT consecutive bins per thread, a shuffle scan per wave, the waves' totals through LDS
+  int cnt[BPT], mysum = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(acc, d);
-      if (lane >= d) acc += up;
-    }
-    excl = acc - cnt + (tid >= 64 ? nfit_all : 0);
+  for (int q = 0; q < BPT; ++q) {
+    const int bin = BPT * tid + q;
+    cnt[q] = bin < QMPC_SO_BINS ? hist[bin] : 0;
+    mysum += cnt[q];
   }
-  __syncthreads();  // (everybody has read the wave totals and the counts)
-  if (tid < 128) hist[tid] = excl;
+  int acc = mysum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(acc, d);
+    if (lane >= d) acc += up;
+  }
+  if (lane == 63) wcnt[32 + wv] = acc;
+  __syncthreads();  // (everybody has read the counts; the waves' totals are there)
+  int off = acc - mysum;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) off += (w < wv) ? wcnt[32 + w] : 0;
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    const int bin = BPT * tid + q;
+    if (bin < QMPC_SO_BINS) hist[bin] = off;
+    off += cnt[q];
+  }
   __syncthreads();
   int runf = fbase, runh = nfit_all + hbase;
   for (int base = lo; base < hi; base += 64) {
     const int i = base + lane;
-    const int key = (i < hi) ? (int)keys[i] : 0xff;
-    const bool fit = key < 64, hand = key >= 64 && key < 128;
+    const int key = (i < hi) ? (int)keys[i] : 0xffff;
+    const bool fit = key < 512, hand = key >= 512 && key < QMPC_SO_BINS;
     const unsigned long long mf = __ballot(fit), mh = __ballot(hand);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (fit) place[runf + __popcll(mf & below)] = (unsigned short)i;
@@ -3582,7 +3653,9 @@ __global__ __launch_bounds__(Cfg<RB>::NT_LAUNCH, Cfg<RB>::MIN_WAVES) void qmpc_s
       else if ((int)blockIdx.x >= P.so_first || (int)blockIdx.x < P.so_nseg * (QMPC_SO_HEAD + 1)) rid = size_order_take(P);
     }
     __builtin_assume(tid0 >= 0 && tid0 < Cfg<RB>::NT);
-    solve_robot<RB, CMD, WARM>(rid, tid0, S, P);
+    // (the first class of a chain: the only launch that can be one round.  Not the five-per-CU instantiation: it exists for launches
+    //  of several rounds, and at 96 registers the staging's code in stage 0 costs it spills on the main path)
+    solve_robot<RB, CMD, WARM, RB != 6>(rid, tid0, S, P);
     pool_release<RB>(S, P);
     balance_release<RB>(tid0, S, P);
   } else {

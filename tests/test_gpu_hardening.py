@@ -358,6 +358,26 @@ def test_size_order_changes_the_order_not_the_results(mpc_factory):
         print(f"   size order: B={B} h={b['horizon']} stance hints {stance}: bit-identical (repeated, other batch sizes, reversed, with the hint)")
 
 
+def test_one_round_priority_by_the_proxy_does_not_change_results(mpc_factory):
+    """A launch of ONE round with full CUs and no usable hint stages the sweep's issue priority by the tracking-error proxy: the
+    workgroups that share a CU post (call number, hardness, robot) with an atomic maximum on the CU's word, the one whose entry
+    stands keeps the top priority.  Scheduling only: bit-identical to qmpc_set_size_order(0), call after call (the
+    words keep the previous call's entries; a newer call number beats them)."""
+    for b in (W.make_config(1), W.make_config(2, batch=1024), W.make_config(3, batch=512), W.make_config(4, batch=1000)):
+        B = int(b["batch"])
+        m = mpc_factory(b)
+        m.set_max_stance(int((b["gait"] != 0).sum(1).max()))
+        m.set_order_hint(0)
+        m.set_size_order(0)
+        base = m.solve(b, full=True)
+        m.set_size_order(1)
+        for rep in range(3):
+            res = m.solve(b, full=True)
+            for k in ("grf", "soln", "iters", "status"):
+                assert np.array_equal(res[k], base[k]), (k, B, rep)
+        print(f"   one-round staging: B={B} h={b['horizon']}: bit-identical")
+
+
 def test_size_order_contact_table_pointer_not_aligned(mpc_factory):
     """The builder reads the contact tables with 4-byte loads from an 8-byte aligned base; any other pointer switches the size
     order off for the call (same results, robot = workgroup index)."""
