@@ -18,8 +18,10 @@ Timing: the K-step region of the contract (barrier + torch.cuda.synchronize on b
 ms_per_step_min / _max the spread.  N > 1: `rank_devices` lists every rank's device name, PCI bus id and uuid,
 `rccl_world_size` the size of the RCCL communicator that carried the barriers.
 
-Contract fields (`value`, `ms_per_step`, `roofline`): the BASELINE config's static synthetic inputs, PLAIN launch order
-(qmpc_set_order_hint off) -- the order hint of the library (scheduling by the previous call's iteration counts) would be
+Contract fields (`value`, `ms_per_step`, `roofline`): the BASELINE config's static synthetic inputs, NO order hint
+(qmpc_set_order_hint off) and the library's size order / proxy staging ON (its default since round 6: scheduling by what THIS
+call's own records say -- contact-table size and a tracking-error proxy --, never by a previous solve; `size_order.off_same_inputs`
+is the rate with it off, robot = workgroup index) -- the order hint of the library (scheduling by the previous call's iteration counts) would be
 EXACT here, because every step re-solves the same inputs; it is reported beside the contract fields
 (`order_hint.hinted_same_inputs`), and what a controller really gets from it -- the PREVIOUS MPC cycle's counts -- is measured
 by the `closed_loop` leg: the config continued as a closed-loop rollout (workloads.ConfigRollout), >= 8 consecutive MPC cycles
@@ -55,8 +57,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6        # MI355X vector FP64 (= dense FP64 MFMA peak)
 # how cpu_baseline.all_cores is taken (rounds 1-4: version 1 = one worker per LOGICAL cpu, 256 / 128 of them throttled onto the
 # container's 16-CPU cgroup quota; since round 5: version 2) -- speedups derived from it are comparable within a version only
-BASELINE_METHOD = {"version": 2, "all_cores": "one worker process per PHYSICAL core, pinned, at most the cgroup CPU quota (>= 1)",
-                   "contract_regions": "plain launch order (qmpc_set_order_hint off) since round 5; rounds 1-4: exact hint"}
+BASELINE_METHOD = {"version": 3, "all_cores": "one worker process per PHYSICAL core, pinned, at most the cgroup CPU quota (>= 1)",
+                   "contract_regions": "no order hint (qmpc_set_order_hint off: nothing from a previous solve) since round 5 (rounds 1-4: exact "
+                                       "hint); since round 6 (version 3) with the library's size order / proxy staging on -- scheduling by "
+                                       "this call's own input records; size_order.off_same_inputs = the version-2 quantity"}
 KERNEL_SOURCES = ["quadruped_ctrl_amd/csrc/qmpc_kernels.hip", "quadruped_ctrl_amd/csrc/qmpc_engine.hip",
                   "quadruped_ctrl_amd/csrc/qmpc_wave.h", "quadruped_ctrl_amd/csrc/qmpc_cmd.h",
                   "quadruped_ctrl_amd/csrc/qmpc_device.h"]
@@ -362,6 +366,10 @@ def main():
                          "exact there; 'auto' = the library default, for experiments (the line then says exact_in_contract_regions).  "
                          "Either way the hinted rate on the same inputs and the closed-loop rollout, where the hint is the previous MPC "
                          "cycle's, are measured beside the contract fields")
+    ap.add_argument("--size-order", choices=["on", "off"], default="on",
+                    help="qmpc_set_size_order during the contract regions: 'on' (default, the library's default) = multi-round launches take "
+                         "the robots largest / highest proxy score first, one-round launches stage the sweep's priority per CU by the proxy "
+                         "-- all from this call's own records; 'off' = robot = workgroup index.  The other setting is measured beside it")
     ap.add_argument("--no-extras", "--no-plain-order", dest="no_extras", action="store_true",
                     help="skip the extra regions (hinted same inputs, closed loop): profiling runs -- every launch of the trace is then "
                          "a launch of the contract loop")
@@ -445,6 +453,7 @@ def main():
         mpc.set_robot(9.0, (0.07, 0.26, 0.242), -9.81)   # SparseCMPC.cpp:40
         mpc.set_model(1)
     mpc.set_order_hint(1 if args.order_hint == "auto" else 0)
+    mpc.set_size_order(args.size_order == "on")
     if args.max_iter is not None:
         mpc.settings(max_iter=args.max_iter)
     d = mpc.upload(b)
@@ -570,6 +579,20 @@ def main():
         mpc.set_order_hint(1 - flip)
         for _ in range(2):
             one_step()       # (the contract state again, for the statistics read below)
+        torch.cuda.synchronize(dev)
+
+    # ---- extra: the same K steps with the size order / proxy staging switched the other way (no hint either way)
+    other_size = None
+    if world == 1 and not args.caller_side and not args.no_extras:
+        mpc.set_size_order(args.size_order != "on")
+        for _ in range(max(args.warmup, 2)):
+            one_step()
+        pr = median_region()
+        other_size = {"size_order": "off" if args.size_order == "on" else "on", "value": per_gpu * args.steps / pr, "unit": "QP solves/s",
+                      "ms_per_step": pr / args.steps * 1e3}
+        mpc.set_size_order(args.size_order == "on")
+        for _ in range(2):
+            one_step()
         torch.cuda.synchronize(dev)
 
     # ---- extra: CLOSED LOOP.  The config continued as a rollout (workloads.ConfigRollout: cycle 0 is the config itself, then
@@ -859,6 +882,14 @@ def main():
                                    "previous call's counts would be exact (hinted_same_inputs, an upper bound); what a controller gets "
                                    "-- the previous MPC cycle's counts -- is the closed_loop object",
                            ("hinted_same_inputs" if args.order_hint == "off" else "plain_order"): other_order},
+            "size_order": {"mode_in_contract_regions": args.size_order,
+                           "what": "qmpc_set_size_order (on by default in the library): without a usable hint, launches of several rounds take the "
+                                   "robots that fit the first class largest first and, among equals, highest proxy score first (robots handed on: by "
+                                   "the score, among their own places), the permutation built inside the launch; launches of one round with full CUs "
+                                   "stage the sweep's issue priority per CU by the score.  Everything from THIS call's input records (contact "
+                                   "tables, tracking error of the coasting state, support asymmetry): nothing from a previous solve.  Results "
+                                   "are bit-identical either way (tests)",
+                           ("off_same_inputs" if args.size_order == "on" else "on_same_inputs"): other_size},
             "closed_loop": closed_loop,
             "tail": tail,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

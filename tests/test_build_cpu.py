@@ -43,10 +43,11 @@ def test_kernel_register_budgets(tmp_path):
     for k, v in {**solve1, **solve4}.items():
         warm = "ELb1ELb0EEv" in k or "ELb1ELb1EEv" in k    # <RB, CMD, WARM, LISTED>: the optional warm-start instantiations
         # (round 6: the list-consuming COMMAND-mode instantiation of the 96-row class -- qmpc_solve_commands behind a 64-row
-        #  first class -- parks one dword in scratch in its PROLOGUE (the wave-placement code, once per workgroup, before the
-        #  robot loop: the scalar registers it spills to a VGPR lane push the thread id out); nothing inside the robot loop)
-        prologue_only = k.startswith("_Z17qmpc_solve_kernelILi4ELb1ELb0ELb1E")
-        assert v["scratch"] <= (32 if warm else (8 if prologue_only else 0)), (k, v)
+        #  first class, at the 128-register limit with 139 scalar registers spilled to VGPR lanes -- parks three dwords in scratch:
+        #  two stores and two loads per robot, between the sweep and the engine (the parameter block grew by the size order's
+        #  fields); every other instantiation of the two classes: none)
+        few_per_robot = k.startswith("_Z17qmpc_solve_kernelILi4ELb1ELb0ELb1E")
+        assert v["scratch"] <= (32 if warm else (16 if few_per_robot else 0)), (k, v)
         assert v["vgpr"] <= 128, (k, v)                    # 4 waves per SIMD: 4 (class 1) / 2 (class 4) workgroups per CU
 
 
