@@ -194,7 +194,8 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
  * the SAME robots every MPC cycle, and a robot that needed many active-set iterations 26 ms ago needs many now: with
  * mode 1 (default) every one-kernel solve leaves its iteration count in a per-handle array, and a call of the same batch
  * size whose first size class is launched over more robots than it has resident workgroups takes the robots in the order
- * of those counts, longest first (one counting-sort kernel of a few microseconds in front of the call); a launch of ONE round
+ * of those counts, longest first (the permutation is built inside the launch by its first workgroups since round 6: no kernel in
+ * front of the call); a launch of ONE round
  * (everybody starts at once) uses them as issue priority instead: the few robots the previous call found hardest keep the
  * highest priority through their Gauss-Jordan sweep, so the launch no longer waits for them.  Scheduling only:
  * a robot's result does not depend on its place (bit-identical, tested; until round 4 there was one exception -- more robots of a
@@ -202,7 +203,9 @@ int qmpc_set_min_stance(qmpc_handle h, int min_stance_footsteps);
  * WHICH of them took the Schur-form fallback depended on the order they ran in -- closed since the slices are recycled within
  * a call); a stale or meaningless hint -- other robots in
  the same rows -- costs nothing but the benefit.  mode 0: off (robot = workgroup index).  Calls captured into a hipGraph
- * and the JCQP alternate do not use it. */
+ * and the JCQP alternate do not use it.  Without usable counts (first call, another batch size, mode 0) the same machinery orders
+ * a launch by what this call's own records say -- contact-table size and a tracking-error proxy --, see qmpc_set_size_order in
+ * qmpc_expert.h (default on; scheduling only as well). */
 int qmpc_set_order_hint(qmpc_handle h, int mode);
 
 /* Everything else the library exports lives in two companion headers, so that this one is the surface a caller needs:

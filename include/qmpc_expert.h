@@ -57,15 +57,22 @@ int qmpc_set_block_start(qmpc_handle h, int on);
  * (its max_batch and stance hints), never of a call's size (since round 5 also for chains with larger classes behind). */
 int qmpc_set_dense(qmpc_handle h, int mode);
 
-/* Size order (default on).  A launch of several rounds of workgroups ends with whichever long robot started last.  When no
- * order hint is usable (first call, another batch size, qmpc_set_order_hint off) the first size class of the chain takes, from
- * about 1.5 rounds on, the robots that FIT it largest first by their contact tables (reduced size = 3 x stance foot-steps: the
- * sweep is that many half-steps long and the smaller problems' iteration counts have the shorter tail), robots it only hands
- * on keep their place; the permutation is built inside the launch by its first workgroup while the first rounds are solved --
- * no kernel in front of the call, no host work.  Scheduling only: bit-identical results (tested).  Not used by
- * one-round launches, handles whose stance hints say every robot has the same size (qmpc_set_min_stance == qmpc_set_max_stance),
- * command mode (the contact table is generated in the kernel), captured calls, the JCQP alternate, or a contact-table pointer
- * that is not 8-byte aligned.  on = 0: robot = workgroup index. */
+/* Size order / proxy staging (default on).  A launch of several rounds of workgroups ends with whichever long robot
+ * started last, a launch of one round with whichever robot iterates longest.  When no order hint is usable (first call, another
+ * batch size, qmpc_set_order_hint off) the library schedules by what THIS call's input records say about a robot's cost: its
+ * reduced size (3 x stance foot-steps: the sweep is that many half-steps long) and a score that follows the active-set iteration
+ * count with a correlation of ~0.7 on the BASELINE workloads (0.2 - 0.5 on closed-loop rollouts it was not fitted on): the tracking
+ * error the coasting state would have at the end of the horizon, times the early stance foot-steps, plus a term for a long first
+ * support phase that cannot balance gravity's moment without friction near its limit (pacing, bounding).
+ *   - several rounds: from about 1.5 rounds on (and within the last five rounds of the launch) the first class takes the robots that
+ *     FIT it largest first, highest score first among equals; robots it only hands on keep to their own places and are ordered among
+ *     themselves by the score (the next class's queue is filled in dispatch order).  The permutation is built inside the launch
+ *     by its first workgroups while the first rounds are solved -- no kernel in front of the call, no host work;
+ *   - one round with full CUs: the workgroups that share a CU post their score with one atomic maximum on the CU's word; the one
+ *     whose entry stands keeps the highest issue priority through its sweep.
+ * Scheduling only: bit-identical results (tested).  Not used by command mode (the contact table is generated in the kernel),
+ * captured calls, the JCQP alternate, or a contact-table pointer that is not 8-byte aligned.  on = 0: robot = workgroup index,
+ * everybody yields alike. */
 int qmpc_set_size_order(qmpc_handle h, int on);
 
 /* Work items are a BOUNDED pool per class -- min(max_batch, 4096 / 3072 / 1024) items of 128 KiB / 288 KiB / 1.53 MiB for

@@ -193,10 +193,16 @@ __device__ __forceinline__ unsigned qmpc_stance_set(const uint32_t w) {  // the 
   const uint32_t t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // bit 7 of every nonzero byte
   return ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
 }
+// demand (DEMAND = true only: the one-round staging's gate): the same error rows on a FORCE scale, sum_k sqrt(Q_k / alpha) |e_k + T de_k|
+//   in units of the robot's weight, times first3 -- what the regulator would ask of the feet.  The score orders robots among
+//   themselves; whether ANY of them will meet a bound it cannot say (SparseCMPC's parameters -- weights 5 - 25 x smaller, mu = 1 --
+//   on configs[1]'s states: mean iteration count 0.01 instead of 2.1, the scores are the same).  On configs[1] every robot with six
+//   or more iterations has demand >= 11.7; with the sparse model's parameters nobody exceeds 10.7.
 struct QmpcKeys {
   int nst;
-  float score;
+  float score, demand, pattern;
 };
+template <bool DEMAND = false>
 __device__ __forceinline__ QmpcKeys qmpc_robot_keys(const QmpcParams& P, const int i) {
   const int h = P.horizon;
   // (4 h bytes per robot, the base 4-byte aligned: the host checks)
@@ -226,15 +232,19 @@ __device__ __forceinline__ QmpcKeys qmpc_robot_keys(const QmpcParams& P, const i
   const float T = (float)h * (float)P.dt;
   const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
   const float x0[3] = {2.f * (qw * qx + qy * qz), 2.f * (qw * qy - qz * qx), P.yaw[i]};
-  float acc = 0.f, wsum = 1e-30f;
+  float acc = 0.f, wsum = 1e-30f, dem = 0.f;
+  const float ialpha = DEMAND ? 1.f / (P.alpha[(size_t)i * P.alpha_stride] + 1e-30f) : 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float er = (x0[k] - tr[k]) + T * (P.w[(size_t)i * 3 + k] - tr[6 + k]);
     const float ep = (P.p[(size_t)i * 3 + k] - tr[3 + k]) + T * (P.v[(size_t)i * 3 + k] - tr[9 + k]);
     acc += wt[k] * __builtin_fabsf(er) + wt[3 + k] * __builtin_fabsf(ep);
     wsum += wt[k] + wt[3 + k];
+    if (DEMAND) dem += __builtin_sqrtf(wt[k] * ialpha) * __builtin_fabsf(er) + __builtin_sqrtf(wt[3 + k] * ialpha) * __builtin_fabsf(ep);
   }
   float score = acc / wsum * (float)first3;
+  const float demand = DEMAND ? dem * (float)first3 / ((float)P.mass * __builtin_fabsf((float)P.gravity) + 1e-30f) : 0.f;
+  float pattern = 0.f;
   if (set0 != 0u) {
     const float* r = P.r + (size_t)i * 12;  // r[axis * 4 + foot]
     float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -252,9 +262,80 @@ __device__ __forceinline__ QmpcKeys qmpc_robot_keys(const QmpcParams& P, const i
     const float sat = __builtin_sqrtf(cx * cx + cy * cy) * (float)P.mu_inv / (cz > 1e-3f ? cz : 1e-3f);
     const float sa = sat > 0.6f ? (sat < 1.f ? sat : 1.f) : 0.f;
     const float pat = (float)run * sa - 1.5f;
-    score += 0.15f * (pat > 0.f ? pat : 0.f);
+    pattern = pat > 0.f ? pat : 0.f;
+    score += 0.15f * pattern;
   }
-  return {nst, score};
+  return {nst, score, demand, pattern};
+}
+// The same keys of ONE robot evaluated by a whole wave (the one-round staging: a single lane's 250 dependent instructions cost
+// every workgroup 1.5 - 3 k cycles of stage 0, whichever wave they ran on): lane k takes segment k of the contact table, lanes 0..5
+// one error row each, lanes 0..11 one foot coordinate each; ballots and three-step butterflies put them together.  All lanes of the
+// wave must call it; the result is uniform.
+__device__ __forceinline__ QmpcKeys qmpc_robot_keys_wave(const QmpcParams& P, const int i, const int lane) {
+  const int h = P.horizon;
+  const uint32_t* g4 = reinterpret_cast<const uint32_t*>(P.gait + (size_t)i * 4 * h);
+  // (every load first: the feet's coordinates do not wait for the stance set they are going to be masked with)
+  const uint32_t graw = (lane < h) ? g4[lane] : 0u;
+  const float rraw = (lane < 12) ? P.r[(size_t)i * 12 + lane] : 0.f;  // r[axis * 4 + foot]
+  const unsigned m = qmpc_stance_set(graw);
+  int nst = 0, first3 = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const unsigned long long bf = __ballot((m >> f) & 1u);
+    nst += __popcll(bf);
+    first3 += __popcll(bf & 7ull);
+  }
+  const unsigned long long nz = __ballot(m != 0u);
+  unsigned set0 = 0u;
+  int run = 0;
+  if (nz != 0ull) {  // (uniform)
+    const int k0 = __builtin_ctzll(nz);
+    set0 = (unsigned)__builtin_amdgcn_readlane((int)m, k0);
+    const unsigned long long ne = ~(__ballot(m == set0 && lane < h) >> k0);
+    run = ne ? __builtin_ctzll(ne) : 64;
+    run = run < h - k0 ? run : h - k0;
+  }
+  // error rows: lane 0..2 orientation k, lane 3..5 position k
+  const int k = (lane < 3) ? lane : (lane < 6 ? lane - 3 : 0);
+  const bool rot = lane < 3, row = lane < 6;
+  const float* q = P.q + (size_t)i * 4;
+  const float* tr = P.traj + (size_t)i * 12 * h;
+  const float T = (float)h * (float)P.dt;
+  const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  const float ang = (k == 0) ? 2.f * (qw * qx + qy * qz) : (k == 1 ? 2.f * (qw * qy - qz * qx) : P.yaw[i]);
+  const float x0 = rot ? ang : P.p[(size_t)i * 3 + k];
+  const float xd = rot ? P.w[(size_t)i * 3 + k] : P.v[(size_t)i * 3 + k];
+  const float e = (x0 - tr[(rot ? 0 : 3) + k]) + T * (xd - tr[(rot ? 6 : 9) + k]);
+  const float wk = P.weights[(size_t)i * P.weights_stride + (rot ? 0 : 3) + k];
+  const float ialpha = 1.f / (P.alpha[(size_t)i * P.alpha_stride] + 1e-30f);
+  float acc = row ? wk * __builtin_fabsf(e) : 0.f;
+  float wsum = row ? wk : 0.f;
+  float dem = row ? __builtin_sqrtf(wk * ialpha) * __builtin_fabsf(e) : 0.f;
+#pragma unroll
+  for (int d = 4; d >= 1; d >>= 1) {
+    acc += __shfl_xor(acc, d);
+    wsum += __shfl_xor(wsum, d);
+    dem += __shfl_xor(dem, d);
+  }
+  acc = __shfl(acc, 0);
+  wsum = __shfl(wsum, 0) + 1e-30f;
+  dem = __shfl(dem, 0);
+  float score = acc / wsum * (float)first3;
+  const float demand = dem * (float)first3 / ((float)P.mass * __builtin_fabsf((float)P.gravity) + 1e-30f);
+  float pattern = 0.f;
+  if (set0 != 0u) {  // (uniform)
+    float rv = (lane < 12 && ((set0 >> (lane & 3)) & 1u)) ? rraw : 0.f;
+    rv += __shfl_xor(rv, 1);
+    rv += __shfl_xor(rv, 2);
+    const float inv = 1.f / (float)__builtin_popcount(set0);
+    const float cx = __shfl(rv, 0) * inv, cy = __shfl(rv, 4) * inv, cz = __builtin_fabsf(__shfl(rv, 8) * inv);
+    const float sat = __builtin_sqrtf(cx * cx + cy * cy) * (float)P.mu_inv / (cz > 1e-3f ? cz : 1e-3f);
+    const float sa = sat > 0.6f ? (sat < 1.f ? sat : 1.f) : 0.f;
+    const float pat = (float)run * sa - 1.5f;
+    pattern = pat > 0.f ? pat : 0.f;
+    score += 0.15f * pattern;
+  }
+  return {nst, score, demand, pattern};
 }
 // score -> `per` logarithmic levels per octave from 2^-6 on, `levels` of them, HARDEST = 0 (a NaN: the easiest)
 __device__ __forceinline__ int qmpc_score_level(const float score, const float per, const int levels) {
@@ -510,25 +591,8 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     hfloor = hard ? 3 : ((mine >= PK.hint_hard && 5 * mine >= 2 * top && ge <= 4) ? 2 : 0);
   }
 
-  // ONE-ROUND launch without a usable hint (prio_cu != nullptr; DESIGN 13): the workgroups that share a CU compete for its issue
-  // slots, and the CU is done when the LAST of them is -- the one that iterates longest.  Which one that will be is guessed from
-  // the tracking-error proxy (qmpc_robot_keys: correlation with the iteration count 0.69 ... 0.76 -- configs[1]'s
-  // 13-iteration robot is third of 1024): a thread that has nothing else to do in stage 0 evaluates it right away, beside
-  // everybody's loads, and posts (call number, hardness, robot) with ONE atomic maximum on its CU's word (four arrivals per word,
-  // served by the XCD's L2; a newer call's number beats whatever an older call left: nothing to reset) ...
   unsigned long long prio_mine = 0ull;
   unsigned long long* prio_word = nullptr;
-  if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
-    if (PK.prio_cu && tid == NT - 1) {
-      unsigned hwid, xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      prio_word = PK.prio_cu + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu));
-      const int pb = qmpc_score_level(qmpc_robot_keys(PK, rid).score, 6.f, 64);
-      prio_mine = ((unsigned long long)PK.prio_tag << 32) | ((unsigned long long)(63 - pb) << 24) | (unsigned)(rid & 0xffffff);
-      __hip_atomic_fetch_max(prio_word, prio_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   // ------------------------------------------------------------ stage 0
   // Every global load of the robot's record is issued up front (one memory
   // latency for the whole stage); then: contact table -> compact stance list
@@ -654,6 +718,32 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
     g_ct1 = PK.ctab[1 * hh + tid];
     g_ct5 = PK.ctab[5 * hh + tid];
     g_ct8 = PK.ctab[8 * hh + tid];
+  }
+  // ONE-ROUND launch without a usable hint (prio_cu != nullptr; DESIGN 13): the workgroups that share a CU compete for its issue
+  // slots, and the CU is done when the LAST of them is -- the one that iterates longest.  Which one that will be is guessed from
+  // the robot's keys (qmpc_robot_keys: correlation of the score with the iteration count 0.69 ... 0.76 -- configs[1]'s 13-iteration
+  // robot is third of 1024): wave 1 (which only copies tables in stage 0: the stance list and M_b / N_b are wave 0's, the
+  // transcendental-heavy error rows waves 2 - 3's) evaluates them HERE, behind the issue of its own loads of this stage (in front of them it put a second memory round trip
+  // into the stage: +2.8 k cycles for everybody), all its lanes together
+  // (qmpc_robot_keys_wave), and its last lane posts (call number, score level, robot) with ONE atomic maximum on its CU's word
+  // (four arrivals per word, served by the XCD's L2; a newer call's number beats whatever an older call left: nothing to reset) ...
+  if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
+    if (PK.prio_cu && (tid >> 6) == 1) {  // (wave 1, all lanes; its last lane posts)
+      const QmpcKeys kk = qmpc_robot_keys_wave(PK, rid, lane);
+      // (posted only by a robot that is likely to meet its bounds at all: where nobody does, lifting one robot of four over its
+      //  neighbours only delays the other three -- SparseCMPC's parameters on configs[1]'s states: -9 %)
+      if (tid == 127) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        prio_word = PK.prio_cu + (((xcc & 7u) << 8) | ((hwid >> 8) & 0xffu));
+        if (kk.demand >= 12.f || kk.pattern > 0.5f) {
+          const int pb = qmpc_score_level(kk.score, 6.f, 64);
+          prio_mine = ((unsigned long long)PK.prio_tag << 32) | ((unsigned long long)(63 - pb) << 24) | (unsigned)(rid & 0xffffff);
+          __hip_atomic_fetch_max(prio_word, prio_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
   }
   // Every load above is in flight now.  The compiler otherwise sinks the first use
   // of each value (a conversion) into the conditional block of its load and waits for
@@ -813,8 +903,10 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   // ... and a stage later reads the word back: the robot whose entry stands is the CU's hardest and keeps the top priority through
   // its sweep (S.prio_rank = 0), the others yield as they advance, as ever.  The barriers of stage 1 publish it
   if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
-    if (PK.prio_cu && tid == NT - 1)
-      S.prio_rank = (__hip_atomic_load(prio_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prio_mine) ? 0 : 1;
+    if (PK.prio_cu && tid == 127) {  // 0: this robot's entry stands; 1: another robot's of this call; 2: nobody on this CU posted
+      const unsigned long long pv = __hip_atomic_load(prio_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      S.prio_rank = (prio_mine != 0ull && pv == prio_mine) ? 0 : ((unsigned)(pv >> 32) == PK.prio_tag ? 1 : 2);
+    }
   }
   {
     const double keep0[2] = {(double)g_alpha, x_drag};
@@ -1573,7 +1665,7 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
       if (QMPC_DBG_ITER == 0 && dbg_clk && tid == 0) dbg_clk[14] = rank;  // (profiling hook)
       hard = rank == 0;
       hfloor = hard ? 3 : 0;
-      staged = true;
+      staged = rank < 2;  // (nobody posted: everybody yields as in an unstaged launch)
     }
   }
   if constexpr (C::C1) {
