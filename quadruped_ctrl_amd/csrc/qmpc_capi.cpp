@@ -175,7 +175,8 @@ struct qmpc_ctx {
   unsigned so_call = 0;
   unsigned long long* d_prio_cu = nullptr;  // [2048] one-round launches without a hint: one word per CU (qmpc_device.h: prio_cu)
   unsigned prio_call = 0;
-  int so_first_pct = 50;
+  int so_first_pct = 0, so_first_pct_hint = 50;  // the unsorted head beyond the first round, % of a round: keys from the records / from the hint
+  int so_min_div = 8;     // at least a round / so_min_div robots to order (measured 2 / 4 / 8 on batches of 1.1 ... 2.5 rounds: no loss anywhere, +4 ... +13 % at 1.4 rounds)
   int so_tail_rounds = 5;
   int hint_prepass = 0;  // 1: the order hint's permutation by a sort kernel in front of the call (as until round 6)
   int hint_batch = 0;           // batch size of the call that wrote d_hint_iters (0: none yet)
@@ -311,10 +312,12 @@ int qmpc_create(int device_id, int max_batch, int max_horizon, qmpc_handle* out)
   {
     const char* ns = std::getenv("QMPC_NO_SPLIT");
     c->split = (ns && ns[0] == '1') ? 0 : 1;
+    const char* sm = std::getenv("QMPC_SO_MIN_DIV");
+    if (sm && std::atoi(sm) > 0) c->so_min_div = std::atoi(sm);
     const char* st = std::getenv("QMPC_SO_TAIL_ROUNDS");
     if (st && std::atoi(st) > 0) c->so_tail_rounds = std::atoi(st);
     const char* sf = std::getenv("QMPC_SO_FIRST_PCT");  // (measurement knob: the unsorted head of a size-ordered launch, % of a round beyond the first)
-    if (sf) c->so_first_pct = std::atoi(sf);
+    if (sf) c->so_first_pct = c->so_first_pct_hint = std::atoi(sf);
     const char* hp = std::getenv("QMPC_HINT_PREPASS");
     if (hp) c->hint_prepass = std::atoi(hp);
     const char* hh = std::getenv("QMPC_HINT_HARD");
@@ -1045,16 +1048,18 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         if (c->hint_batch == batch) P.hint_hard = c->hint_hard;
       }
     }
-    // size order: no usable hint, several rounds, contact tables in memory (record mode) and 8-byte aligned (robots of one size
-    // are ordered by the tracking-error proxy instead: the builder decides).  The first 1.5 rounds keep robot = workgroup index: the builders (the first workgroups, one
-    // segment of the rest each) need a few microseconds, and the workgroups that follow robots which are only handed on start
-    // within a few microseconds as well
+    // size order: no usable hint, several rounds, contact tables in memory (record mode) and 8-byte aligned.  The first round keeps
+    // robot = workgroup index (its workgroups start before anything can be known); the builders (the first workgroups, one
+    // segment of the rest each) need a few microseconds, which the workgroups that follow robots only handed on may have to wait
     P.so_order = nullptr;
     const bool by_size = c->size_order && !cmd && P.gait && ((uintptr_t)P.gait & 7u) == 0;
     if (!listed && !capturing && !P.admm_mode && !P.order && (use_hint_keys || by_size)) {
       const int res = qmpc_resident_blocks(kcls);
       if (res > 0 && batch > res) {
-        const int head = (int)((long long)res * c->so_first_pct / 100);
+        // (the unsorted head beyond the first round: none by size -- measured 0 / 15 / 30 / 50 % of a round: 0 is best or equal
+        //  everywhere, +2.6 % on configs[2] --, half a round by the hint's counts: 0 / 25 / 50 %: 3.92e7 / 3.96e7 / 4.05e7 on
+        //  configs[2] with exact counts, equal elsewhere -- robots of one COUNT side by side run their engine phases together)
+        const int head = (int)((long long)res * (use_hint_keys ? c->so_first_pct_hint : c->so_first_pct) / 100);
         const int half = (batch - res) / 2 < head ? (batch - res) / 2 : head;
         P.so_first = (res + half + 7) & ~7;
         // (a launch of many rounds: only its last five are ordered -- a robot lasts three or four rounds at most, so nothing that
@@ -1062,9 +1067,8 @@ int solve_impl(qmpc_ctx* c, int batch, const qmpc_inputs* in, const qmpc_command
         //  with everything ordered)
         if (batch - c->so_tail_rounds * res > P.so_first) P.so_first = (batch - c->so_tail_rounds * res + 7) & ~7;
         const int n = batch - P.so_first;
-        // (fewer than half a round to order: the builders and the sixteen first-round places per segment cost more than the
-        //  order gives -- mixed gaits, 2048 robots on 1280 slots: -5.5 %)
-        if (2 * n >= res && 17 * 8 * ((n + 8 * 4080 - 1) / (8 * 4080)) <= res) {
+        // (next to nothing to order: the builders and the sixteen first-round places per segment cost more than the order gives)
+        if (c->so_min_div * n >= res && 17 * 8 * ((n + 8 * 4080 - 1) / (8 * 4080)) <= res) {
           // strided segments of at most 4096 robots (QMPC_SO_SEG of qmpc_kernels.hip: the builder's LDS scratch)
           // (a multiple of 8, and so_first too: place b of segment j has b % 8 == j % 8 -- readers and builder on one XCD)
           // (QMPC_SO_HEAD = 16 places of the first round per segment on top: 17 nseg workgroups in front of so_first)

@@ -3621,7 +3621,10 @@ __device__ __forceinline__ void size_order_build(const int tid, Smem<RB>& S, con
       key[u] = -1;
       if (i < hi) {
         if (CMD || P.so_hint) {
-          const int d = 63 - P.so_hint[gidx(i)];  // (command mode: the contact table exists in registers only -- hint or nothing)
+          // (command mode: the contact table exists in registers only -- the count or nothing.  The count ALONE also where the
+          //  table is there: joined with the size -- added to it in the sweep's unit, or behind it in the two-level key -- the
+          //  exact hint on configs[2] gives 3.90e7 / 3.94e7 instead of 4.03e7, on configs[4] 2.02e7 instead of 2.17e7)
+          const int d = 63 - P.so_hint[gidx(i)];
           key[u] = 8 * (d < 0 ? 0 : d);
         } else {
           const QmpcKeys kk = qmpc_robot_keys(P, gidx(i));
