@@ -64,7 +64,7 @@ int qmpc_set_dense(qmpc_handle h, int mode);
  * count with a correlation of ~0.7 on the BASELINE workloads (0.2 - 0.5 on closed-loop rollouts it was not fitted on): the tracking
  * error the coasting state would have at the end of the horizon, times the early stance foot-steps, plus a term for a long first
  * support phase that cannot balance gravity's moment without friction near its limit (pacing, bounding).
- *   - several rounds: from about 1.5 rounds on (and within the last five rounds of the launch) the first class takes the robots that
+ *   - several rounds: from the second round on (and within the last five rounds of the launch) the first class takes the robots that
  *     FIT it largest first, highest score first among equals; robots it only hands on keep to their own places and are ordered among
  *     themselves by the score (the next class's queue is filled in dispatch order).  The permutation is built inside the launch
  *     by its first workgroups while the first rounds are solved -- no kernel in front of the call, no host work;
