@@ -344,6 +344,11 @@ __device__ __forceinline__ int qmpc_score_level(const float score, const float p
   return levels - 1 - b;
 }
 
+// (one-round staging: the other robots of a staged CU step back one level from the assembly on -- 0: only in the sweep)
+#ifndef QMPC_STAGE_EARLY
+#define QMPC_STAGE_EARLY 1
+#endif
+
 // Size classes.  RB names the class: 1, 2, 3 = 64 / 128 / 192 padded rows (four column
 // groups of 16 RB columns, 256 RB threads); 4 = the 96-row class between 1 and 2 (four
 // groups of 24 columns, 384 threads, two workgroups per CU) that catches n_r <= 96 --
@@ -1068,6 +1073,13 @@ __device__ __forceinline__ bool solve_one(const int rid, const int tid, Smem<RB>
   }
   __syncthreads();  // ---- barrier 2
   QMPC_TICK(2);
+#if QMPC_STAGE_EARLY
+  // (the robots of a staged CU that are not its hardest step back one level from the assembly on, like the hint's robots after
+  //  stage 0: configs[1] 2.73e7 -> 2.76e7; one level lower still throughout their sweep: no change -- tools/dbg/run_stage_variants.sh)
+  if constexpr (PRIO && !CMD && !ADMM && !BIG && !PHA) {
+    if (PK.prio_cu && __builtin_amdgcn_readfirstlane(S.prio_rank) == 1) __builtin_amdgcn_s_setprio(2);
+  }
+#endif
   {
     const double keep1[2] = {alpha, x_drag};
     (void)keep1;
@@ -3547,7 +3559,7 @@ __device__ __forceinline__ void pool_release(Smem<RB>& S, const QmpcParams& P) {
 // SIZE ORDER: a launch of several rounds of workgroups ends with whichever long robot started last.  What a
 // robot will cost is not known before its inverse exists -- but its record says a good deal (qmpc_robot_keys above): the
 // reduced size n_r = 3 x stance foot-steps (the sweep is n_r / 2 steps long) and a score that follows the iteration count
-// with a correlation of 0.7.  So the workgroups beyond so_first (about 1.5 rounds) take the robots THAT FIT THIS CLASS largest
+// with a correlation of 0.7.  So the workgroups beyond so_first (the host's choice: the second round on) take the robots THAT FIT THIS CLASS largest
 // first and, among equals, highest score first; the robots the class only hands on stay among their own places (bunching those
 // costs more than any order of theirs gives: they hide behind their neighbours' sweeps) and are ordered among themselves by
 // the score, for the NEXT class's sake: its queue is filled in dispatch order, and that launch (two workgroups per CU, robots

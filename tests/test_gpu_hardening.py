@@ -358,6 +358,28 @@ def test_size_order_changes_the_order_not_the_results(mpc_factory):
         print(f"   size order: B={B} h={b['horizon']} stance hints {stance}: bit-identical (repeated, other batch sizes, reversed, with the hint)")
 
 
+def test_size_order_random_call_sequence(mpc_factory):
+    """One handle, twenty calls of random sizes (one round, a round and a bit, many rounds; random contact tables, so every call
+    has robots that are handed on) with the size order on and the hint off / on: every call bit-identical to the plain-order
+    results of the same robots -- entries, call numbers and CU words of earlier calls are still in the buffers."""
+    big = W.make_config(4, batch=9000)
+    m = mpc_factory(big)
+    m.set_order_hint(0)
+    m.set_size_order(0)
+    base = m.solve(big, full=True)
+    assert ((base["status"] & 47) == 0).all()
+    rng = np.random.default_rng(20260930)
+    m.set_size_order(1)
+    for call in range(20):
+        nb = int(rng.choice([int(rng.integers(900, 1300)), int(rng.integers(1300, 2600)), int(rng.integers(2600, 9001))]))
+        start = int(rng.integers(0, 9000 - nb + 1))
+        idx = np.arange(start, start + nb)
+        m.set_order_hint(int(call % 3 == 2))
+        res = m.solve(_take(big, idx), full=True)
+        for k in ("grf", "soln", "iters", "status"):
+            assert np.array_equal(res[k], base[k][idx]), (k, call, nb, start)
+
+
 def test_one_round_priority_by_the_proxy_does_not_change_results(mpc_factory):
     """A launch of ONE round with full CUs and no usable hint stages the sweep's issue priority by the tracking-error proxy: the
     workgroups that share a CU post (call number, hardness, robot) with an atomic maximum on the CU's word, the one whose entry
