@@ -308,27 +308,30 @@ __device__ __forceinline__ QmpcKeys qmpc_robot_keys_wave(const QmpcParams& P, co
   const float e = (x0 - tr[(rot ? 0 : 3) + k]) + T * (xd - tr[(rot ? 6 : 9) + k]);
   const float wk = P.weights[(size_t)i * P.weights_stride + (rot ? 0 : 3) + k];
   const float ialpha = 1.f / (P.alpha[(size_t)i * P.alpha_stride] + 1e-30f);
-  float acc = row ? wk * __builtin_fabsf(e) : 0.f;
-  float wsum = row ? wk : 0.f;
-  float dem = row ? __builtin_sqrtf(wk * ialpha) * __builtin_fabsf(e) : 0.f;
+  // (the six rows and the twelve foot coordinates are put together with v_readlane -- uniform scalars, a few cycles each and
+  //  independent of one another; butterflies through the LDS crossbar, ~17 dependent ds_bpermute, cost the stage ~1 k cycles)
+  const float t_acc = wk * __builtin_fabsf(e), t_dem = __builtin_sqrtf(wk * ialpha) * __builtin_fabsf(e);
+  float acc = 0.f, wsum = 1e-30f, dem = 0.f;
 #pragma unroll
-  for (int d = 4; d >= 1; d >>= 1) {
-    acc += __shfl_xor(acc, d);
-    wsum += __shfl_xor(wsum, d);
-    dem += __shfl_xor(dem, d);
+  for (int l = 0; l < 6; ++l) {
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_acc), l));
+    wsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wk), l));
+    dem += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_dem), l));
   }
-  acc = __shfl(acc, 0);
-  wsum = __shfl(wsum, 0) + 1e-30f;
-  dem = __shfl(dem, 0);
   float score = acc / wsum * (float)first3;
   const float demand = dem * (float)first3 / ((float)P.mass * __builtin_fabsf((float)P.gravity) + 1e-30f);
   float pattern = 0.f;
   if (set0 != 0u) {  // (uniform)
-    float rv = (lane < 12 && ((set0 >> (lane & 3)) & 1u)) ? rraw : 0.f;
-    rv += __shfl_xor(rv, 1);
-    rv += __shfl_xor(rv, 2);
+    float c3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const float rv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rraw), 4 * ax + f));
+        c3[ax] += ((set0 >> f) & 1u) ? rv : 0.f;
+      }
     const float inv = 1.f / (float)__builtin_popcount(set0);
-    const float cx = __shfl(rv, 0) * inv, cy = __shfl(rv, 4) * inv, cz = __builtin_fabsf(__shfl(rv, 8) * inv);
+    const float cx = c3[0] * inv, cy = c3[1] * inv, cz = __builtin_fabsf(c3[2] * inv);
     const float sat = __builtin_sqrtf(cx * cx + cy * cy) * (float)P.mu_inv / (cz > 1e-3f ? cz : 1e-3f);
     const float sa = sat > 0.6f ? (sat < 1.f ? sat : 1.f) : 0.f;
     const float pat = (float)run * sa - 1.5f;
