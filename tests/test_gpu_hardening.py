@@ -385,7 +385,8 @@ def test_one_round_priority_by_the_proxy_does_not_change_results(mpc_factory):
     workgroups that share a CU post (call number, hardness, robot) with an atomic maximum on the CU's word, the one whose entry
     stands keeps the top priority.  Scheduling only: bit-identical to qmpc_set_size_order(0), call after call (the
     words keep the previous call's entries; a newer call number beats them)."""
-    for b in (W.make_config(1), W.make_config(2, batch=1024), W.make_config(3, batch=512), W.make_config(4, batch=1000)):
+    for b in (W.make_config(1), W.make_config(2, batch=1024), W.make_config(3, batch=512), W.make_config(4, batch=1000),
+              W.make_standing(256, 10), W.make_standing(250, 14)):  # (the 128- / 192-row classes' one-kernel path: one workgroup per CU)
         B = int(b["batch"])
         m = mpc_factory(b)
         m.set_max_stance(int((b["gait"] != 0).sum(1).max()))
