@@ -65,6 +65,12 @@ int qmpc_debug_read_counts(qmpc_handle h, int* host768);
  * the kernel's phase boundaries (NULL = off). */
 int qmpc_set_debug_clock(qmpc_handle h, long long* clk_dev);
 
+/* What the scheduling of DESIGN.md 13 reads from a batch's records, as the kernels evaluate it (qmpc_robot_keys): per robot the
+ * stance foot-steps, the score that orders launches and the force-scaled demand that gates the one-round staging.  DEVICE
+ * pointers [batch]; enqueued on `stream`.  tests/test_gpu_hardening.py pins it to the numpy statement of the formula. */
+int qmpc_debug_keys(qmpc_handle h, int batch, const qmpc_inputs* in, int32_t* nst_dev, float* score_dev, float* demand_dev,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

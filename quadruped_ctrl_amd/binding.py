@@ -25,7 +25,7 @@ EXPORTS = ["qmpc_abi_version", "qmpc_last_error", "qmpc_create", "qmpc_destroy",
            "qmpc_forces_to_body", "qmpc_solve_commands", "qmpc_set_min_stance",
            "qmpc_set_debug_aux", "qmpc_set_debug_overflow_slices", "qmpc_solve_sharded", "qmpc_set_leg_geometry",
            "qmpc_leg_kinematics", "qmpc_leg_torques", "qmpc_swing_trajectory", "qmpc_set_warm_start", "qmpc_settings_jcqp", "qmpc_kf_init", "qmpc_kf_step", "qmpc_set_model",
-           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_size_order", "qmpc_set_order_hint", "qmpc_set_debug_balance",
+           "qmpc_max_horizon", "qmpc_set_debug_pool_busy", "qmpc_set_split", "qmpc_reserve", "qmpc_set_debug_engine_events", "qmpc_set_chunks", "qmpc_set_block_start", "qmpc_debug_read_item", "qmpc_debug_read_counts", "qmpc_set_dense", "qmpc_set_size_order", "qmpc_debug_keys", "qmpc_set_order_hint", "qmpc_set_debug_balance",
            "qmpc_set_warm_start_min_iters", "qmpc_set_debug_overflow_spin"]
 
 KF_FIELDS = ("xhat", "P", "r_body", "a_world", "omega_body", "contact_phase", "leg_p", "leg_v", "position", "v_world", "v_body")
@@ -128,6 +128,7 @@ def load_library():
         lib.qmpc_set_chunks.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_dense.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_size_order.argtypes = [C.c_void_p, C.c_int]
+        lib.qmpc_debug_keys.argtypes = [C.c_void_p, C.c_int, C.POINTER(Inputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.qmpc_set_order_hint.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_debug_balance.argtypes = [C.c_void_p, C.c_int]
         lib.qmpc_set_block_start.argtypes = [C.c_void_p, C.c_int]
@@ -516,6 +517,22 @@ class BatchedConvexMPC:
         """0 / 1 / 2: the 64-row class's five-workgroups-per-CU instantiation never / automatic (handles of 2048+ robots; see
         include/qmpc.h) / whenever that class is the whole chain."""
         self._check(self.lib.qmpc_set_dense(self.h, int(mode)), "qmpc_set_dense")
+
+    def debug_keys(self, b):
+        """The scheduling keys of DESIGN 13 as the kernels evaluate them: (stance foot-steps, score, demand) per robot (numpy)."""
+        t = self.torch
+        d = self.upload(b)
+        B = d["batch"]
+        o = self.alloc_outputs(B)
+        inp, _ = self.make_args(d, o)
+        nst = t.empty((B,), dtype=t.int32, device=self.device)
+        score = t.empty((B,), dtype=t.float32, device=self.device)
+        demand = t.empty((B,), dtype=t.float32, device=self.device)
+        s = t.cuda.current_stream(self.device)
+        self._check(self.lib.qmpc_debug_keys(self.h, B, C.byref(inp), nst.data_ptr(), score.data_ptr(), demand.data_ptr(),
+                                             C.c_void_p(s.cuda_stream)), "qmpc_debug_keys")
+        t.cuda.synchronize(self.device)
+        return nst.cpu().numpy(), score.cpu().numpy(), demand.cpu().numpy()
 
     def set_size_order(self, on):
         """0 / 1: without a usable order hint, multi-round launches take the robots in blockIdx order / the robots that fit

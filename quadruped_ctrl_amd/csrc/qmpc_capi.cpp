@@ -85,6 +85,7 @@ static hipError_t qmpc_launch(int rb, const QmpcParams* P, int grid, hipStream_t
   }
   return hipErrorInvalidValue;
 }
+extern "C" hipError_t qmpc_launch_keys(const QmpcParams* P, int* nst, float* score, float* demand, hipStream_t stream);
 extern "C" hipError_t qmpc_launch_pack(const qmpc_command* c, const qmpc_record* rec, int batch, int horizon, float dt_mpc,
                                        hipStream_t stream);
 extern "C" hipError_t qmpc_launch_f2b(const float* r_body, const float* grf, float* f_ff, int batch, hipStream_t stream);
@@ -565,6 +566,31 @@ int qmpc_set_dense(qmpc_handle c, int mode) {
 int qmpc_set_debug_balance(qmpc_handle c, int mode) {
   if (!c || mode < 0 || mode > 2) return QMPC_ERR_ARG;
   c->bal_debug = mode;
+  return QMPC_OK;
+}
+
+int qmpc_debug_keys(qmpc_handle c, int batch, const qmpc_inputs* in, int32_t* nst_dev, float* score_dev, float* demand_dev,
+                    void* stream_) {
+  if (!c || !in || !nst_dev || !score_dev || !demand_dev) return QMPC_ERR_ARG;
+  if (!c->is_setup) return QMPC_ERR_STATE;
+  if (batch < 0 || batch > c->max_batch) return QMPC_ERR_ARG;
+  if (batch == 0) return QMPC_OK;
+  if (!in->p || !in->v || !in->q || !in->w || !in->r || !in->yaw || !in->traj || !in->gait || !in->weights || !in->alpha ||
+      ((uintptr_t)in->gait & 3u))
+    return QMPC_ERR_ARG;
+  DeviceGuard g(c->device);
+  QmpcParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.p = in->p; P.v = in->v; P.q = in->q; P.w = in->w; P.r = in->r; P.yaw = in->yaw;
+  P.traj = in->traj; P.gait = in->gait; P.weights = in->weights; P.alpha = in->alpha;
+  P.weights_stride = in->weights_stride;
+  P.alpha_stride = in->alpha_stride;
+  P.batch = batch; P.horizon = c->horizon;
+  P.dt = c->dt;
+  P.mu_inv = (double)(1.f / (float)c->mu);
+  P.mass = c->mass;
+  P.gravity = c->gravity;
+  HIP_TRY(c, qmpc_launch_keys(&P, nst_dev, score_dev, demand_dev, (hipStream_t)stream_));
   return QMPC_OK;
 }
 

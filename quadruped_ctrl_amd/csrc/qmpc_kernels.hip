@@ -4015,6 +4015,20 @@ int resident_class() {
     return hipGetLastError();                                                                              \
   }
 #if !defined(QMPC_RB) || QMPC_RB == 1
+// test hook (qmpc_debug_keys): what qmpc_robot_keys says about every robot of a batch -- the size order's and the one-round
+// staging's keys, as the kernels evaluate them
+__global__ void qmpc_keys_kernel(const QmpcParams P, int* __restrict__ nst, float* __restrict__ score, float* __restrict__ demand) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= P.batch) return;
+  const QmpcKeys k = qmpc_robot_keys<true>(P, i);
+  nst[i] = k.nst;
+  score[i] = k.score;
+  demand[i] = k.demand;
+}
+extern "C" hipError_t qmpc_launch_keys(const QmpcParams* P, int* nst, float* score, float* demand, hipStream_t stream) {
+  hipLaunchKernelGGL(qmpc_keys_kernel, dim3((P->batch + 255) / 256), dim3(256), 0, stream, *P, nst, score, demand);
+  return hipGetLastError();
+}
 QMPC_DEFINE_CLASS(1)
 #endif
 #if !defined(QMPC_RB) || QMPC_RB == 2

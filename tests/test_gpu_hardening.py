@@ -358,6 +358,59 @@ def test_size_order_changes_the_order_not_the_results(mpc_factory):
         print(f"   size order: B={B} h={b['horizon']} stance hints {stance}: bit-identical (repeated, other batch sizes, reversed, with the hint)")
 
 
+def _keys_numpy(b, mass=9.0, gravity=9.8):
+    """The scheduling keys of DESIGN 13.1, stated in numpy (float64): stance foot-steps, score, demand."""
+    B, h = int(b["batch"]), int(b["horizon"])
+    q = b["q"].astype(np.float64)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    x0 = np.concatenate([np.stack([2 * (w * x + y * z), 2 * (w * y - z * x), b["yaw"].astype(np.float64)], 1),
+                         b["p"].astype(np.float64), b["w"].astype(np.float64), b["v"].astype(np.float64)], 1)
+    tr = b["traj"].reshape(B, h, 12).astype(np.float64)[:, 0, :]
+    Q = np.broadcast_to(b["weights"].astype(np.float64).reshape(-1, 12), (B, 12))
+    alpha = np.broadcast_to(b["alpha"].astype(np.float64).reshape(-1), (B,))
+    T = h * float(np.float32(b["dt"]))
+    e = np.abs((x0[:, :6] - tr[:, :6]) + T * (x0[:, 6:] - tr[:, 6:]))       # orientation rows, position rows
+    g = (b["gait"].reshape(B, h, 4) != 0)
+    nst = g.sum((1, 2))
+    first3 = g[:, :3].sum((1, 2))
+    score = (Q[:, :6] * e).sum(1) / Q[:, :6].sum(1) * first3
+    demand = (np.sqrt(Q[:, :6] / alpha[:, None]) * e).sum(1) * first3 / (mass * gravity)
+    r = b["r"].reshape(B, 3, 4).astype(np.float64)
+    mu = float(np.float32(b["mu"]))
+    for i in range(B):
+        ks = np.nonzero(g[i].any(1))[0]
+        if len(ks) == 0:
+            continue
+        k0 = ks[0]
+        run = 1
+        while k0 + run < h and (g[i, k0 + run] == g[i, k0]).all():
+            run += 1
+        c = (r[i][:, g[i, k0]]).mean(1)
+        sat = np.hypot(c[0], c[1]) / (max(abs(c[2]), 1e-3) * mu)
+        sa = min(sat, 1.0) if sat > 0.6 else 0.0
+        score[i] += 0.15 * max(0.0, run * sa - 1.5)
+    return nst, score, demand
+
+
+def test_scheduling_keys_match_the_formula(mpc_factory):
+    """qmpc_debug_keys: the keys the size order and the one-round staging read from the records (qmpc_robot_keys), as the kernels
+    evaluate them, against the numpy statement of DESIGN 13.1 -- stance foot-steps exactly, score and demand to float accuracy --
+    and the claim they rest on: the score follows the active-set iteration count (correlation >= 0.7 on a trot batch and on
+    random contact tables, >= 0.65 on mixed gaits; the size alone: < 0.3)."""
+    for b, floor in ((W.make_config(1), 0.70), (W.make_config(2, batch=2048), 0.65), (W.make_config(4, batch=2048), 0.70), (W.make_config(3, batch=512), 0.60)):
+        m = mpc_factory(b)
+        nst, score, demand = m.debug_keys(b)
+        rn, rs, rd = _keys_numpy(b)
+        assert np.array_equal(nst, rn)
+        assert np.allclose(score, rs, rtol=2e-4, atol=1e-6), float(np.abs(score - rs).max())
+        assert np.allclose(demand, rd, rtol=2e-4, atol=1e-4), float(np.abs(demand - rd).max())
+        it = m.solve(b)["iters"]
+        corr = float(np.corrcoef(score, it)[0, 1])
+        csize = float(np.corrcoef(nst, it)[0, 1]) if nst.std() > 0 else 0.0
+        print(f"   keys: B={b['batch']} h={b['horizon']}: corr(score, iters) {corr:.3f}, corr(size, iters) {csize:.3f}")
+        assert corr >= floor and csize < 0.3, (corr, csize)
+
+
 def test_size_order_random_call_sequence(mpc_factory):
     """One handle, twenty calls of random sizes (one round, a round and a bit, many rounds; random contact tables, so every call
     has robots that are handed on) with the size order on and the hint off / on: every call bit-identical to the plain-order
