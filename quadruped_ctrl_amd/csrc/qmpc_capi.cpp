@@ -279,7 +279,7 @@ int ensure_pools(qmpc_ctx* c);
 
 extern "C" {
 
-int qmpc_abi_version(void) { return 20; }
+int qmpc_abi_version(void) { return 21; }  // 21: qmpc_set_size_order (expert), qmpc_debug_keys (debug) added; no signature changed
 int qmpc_max_horizon(void) { return QMPC_MAX_HORIZON; }
 
 const char* qmpc_last_error(qmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
