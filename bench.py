@@ -792,7 +792,7 @@ def main():
                     "note": "one-round launch: every robot starts at once and the launch ends with the robot that iterates longest.  Floor = "
                             "that robot's fixed part when it has a CU to itself (stamped in a 64-robot launch) + its iterations x the "
                             "cycles per iteration measured there; shader-clock cycles (s_memtime), stamped calls outside the timed regions.  "
-                            "The same kernel reaches reference_equivalent_frac ~0.58 at 16 384 robots (profiles/r05_e_bench_cfg1_b16384.json), "
+                            "The same arithmetic reaches reference_equivalent_frac ~0.68 at 16 384 robots (profiles/r06_zz_bench_cfg1_b16384.json), "
                             "where the tail is amortised over 13 rounds"}
             mpc.set_order_hint(1 if args.order_hint == "auto" else 0)
             for _ in range(2):
